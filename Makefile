@@ -1,0 +1,40 @@
+# Root build: libfamseq_hip.so (HIP, gfx950 only) + the test oracle.
+#   make            -> famseq_amd/lib/libfamseq_hip.so
+#   make oracle     -> oracle/liboracle_bn.so (+ oracle/_ref when /root/reference exists)
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := famseq_amd/csrc
+LIB := famseq_amd/lib/libfamseq_hip.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-result
+
+SRCS := $(CSRC)/bn_kernel.hip $(CSRC)/capi.cpp $(CSRC)/plan.cpp $(CSRC)/model.cpp
+OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
+
+all: $(LIB)
+
+build/%.o: $(CSRC)/% $(wildcard $(CSRC)/*.h) include/famseq_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+# Link step.  The library must bind to whichever HIP runtime the process already uses:
+# PyTorch-ROCm wheels bundle their own runtime under the SONAME "libamdhip64.so", the system
+# ROCm one is "libamdhip64.so.7", and two HIP/HSA runtimes in one process cannot both own the
+# GPU.  So we record the unversioned name as DT_NEEDED (via an empty link-time stub): inside a
+# torch process (torch imported first) it resolves to torch's runtime, elsewhere to
+# /opt/rocm/lib/libamdhip64.so through the RUNPATH.
+build/stub/libamdhip64.so:
+	@mkdir -p build/stub
+	echo "" | gcc -shared -fPIC -x c - -Wl,-soname,libamdhip64.so -o $@
+
+$(LIB): $(OBJS) build/stub/libamdhip64.so
+	@mkdir -p famseq_amd/lib
+	g++ -shared -fPIC -o $@ $(OBJS) -Wl,--no-as-needed -Lbuild/stub -lamdhip64 -Wl,--as-needed \
+	    -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
+
+oracle:
+	$(MAKE) -C oracle all $(if $(wildcard /root/reference/src/family.cpp),ref,)
+
+clean:
+	rm -rf build famseq_amd/lib
+
+.PHONY: all oracle clean

@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py — variant sites/s of the pedigree BN posterior on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ped10|ped5|ped15] [--sites S]
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (famseq_bn_batch_device: single posterior, shortcut
+vote, 3^N enumeration, normalisation, status) over this rank's resident batch of seeded
+synthetic sites.  Inputs and outputs live in HBM for the whole timed
+region.  Sites shard across ranks with no data-path collective (weak scaling: every rank
+holds --sites sites of its own range of the one seeded stream); torch.distributed (RCCL) is
+used only for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     HBM roofline of the enumeration kernel: achieved = algorithmic bytes per launch
+               (24N+1 read + 24N post + 24N single + 1 status per site)
+               / mean kernel time from HIP events on the launch stream; peak 8000 GB/s.
+  fp64_valu    the roofline that actually binds: executed fp64 ops/s vs 39.3 T/s.
+  cpu_baseline the oracle (plain-C port of the reference CPU path) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {  # name -> (BASELINE.json config number, default sites per GPU)
+    "ped5": (1, 1_000_000),
+    "ped10": (2, 10_000_000),
+    "ped15": (4, 20_000),
+}
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TOPS = 39.3   # 78.6 TFLOP/s FMA-counted / 2: this path has no fusable mul+add
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ped10", choices=sorted(WORKLOADS))
+    ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the BASELINE config's size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    ap.add_argument("--option", action="append", default=[], help="famseq_set_option key=value (tuning)")
+    return ap.parse_args()
+
+
+def fp64_ops_per_site(plan):
+    """fp64 operations the kernel executes per site in the enumeration (low tree only:
+    8 per node, (3^L - 1)/2 nodes per lane step), see DESIGN.md."""
+    L, A, J = plan["L"], plan["A"], plan["J"]
+    return 8 * (3 ** L - 1) // 2 * 3 ** (A + J)
+
+
+def host_cores():
+    """CPU share of this process: affinity mask capped by the cgroup CPU quota."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
+
+
+def cpu_baseline(ped, cfg, seconds, n):
+    """The oracle (plain-C port of family.cpp:750-1124) on this host: one thread, then all
+    cores, each on a bounded seeded sample sized by wall time (never by an assumed scaling)."""
+    import numpy as np
+
+    import oracle
+    from famseq_amd import synth
+
+    cores = min(host_cores(), 64)
+    mo, fa = ped.relations()
+    o = oracle.OracleModel(ped.ids, ped.mids, ped.fids, ped.genders)
+    probe = max(1, min(64, int(2e6 / 3 ** n) or 1))
+    lk, fl = synth.gen_batch(mo, fa, probe, cfg)
+    t0 = time.perf_counter()
+    o.bn_batch(lk, fl, threads=1)
+    per_site = (time.perf_counter() - t0) / probe
+
+    def timed(threads, budget):
+        """Slices of ~1 s until `budget` seconds are spent; -> (sites, seconds)."""
+        slice_n = max(threads, int(1.0 / per_site) * threads)
+        lk, fl = synth.gen_batch(mo, fa, slice_n, cfg)
+        done, spent = 0, 0.0
+        while spent < budget:
+            t0 = time.perf_counter()
+            o.bn_batch(lk, fl, threads=threads)
+            spent += time.perf_counter() - t0
+            done += slice_n
+        return done, spent
+
+    n1, t1 = timed(1, min(3.0, seconds / 4))
+    na, ta = timed(cores, seconds)
+    return {"value": na / ta, "unit": "sites/s", "cores": cores, "kind": "port",
+            "sample": "%d seeded %s sites (same generator as the GPU batch) on %d pthreads in %.1f s; "
+                      "1 thread: %d sites in %.1f s" % (na, ped_name(ped), cores, ta, n1, t1),
+            "one_core_sites_per_s": n1 / t1, "configs_per_s_per_core": n1 / t1 * 3 ** n}
+
+
+def ped_name(ped):
+    return "ped%d" % ped.n
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    import famseq_amd as fs
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (a.gpus, a.gpus))
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: libfamseq_hip.so has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg, default_sites = WORKLOADS[a.workload]
+    S = a.sites or default_sites
+    ped = fs.synthetic_pedigree(a.workload)
+    n = ped.n
+    mo, fa = ped.relations()
+    ctx = fs.Context(fs.make_model(ped), device=local)
+    for kv in a.option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    plan = ctx.plan()
+
+    # this rank's own range of the seeded stream, generated straight into HBM
+    lk, flags = fs.synth.gen_batch_torch(mo.tolist(), fa.tolist(), S, cfg, first_site=rank * S, device=dev)
+    post = torch.empty_like(lk)
+    single = torch.empty_like(lk)
+    status = torch.empty(S, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ctx.bn_batch_device(S, lk.data_ptr(), flags.data_ptr(), post.data_ptr(), single.data_ptr(), status.data_ptr(),
+                            stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+
+    # sanity on the timed outputs: generator guarantees full enumeration everywhere
+    bad = int((status != 0).sum().item())
+    rows = post.sum(dim=2)
+    row_err = float((rows - 1).abs().max().item())
+    if bad or not row_err < 1e-9:
+        sys.exit("bench output invalid: %d sites with status != 0, max |rowsum-1| = %g" % (bad, row_err))
+
+    if rank == 0:
+        total_sites = S * world
+        value = total_sites * a.steps / elapsed
+        bytes_per_site = (24 * n + 1) + 24 * n + 24 * n + 1
+        achieved = S * bytes_per_site / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % a.workload)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("sites_per_launch"):
+                traffic = tj["bytes_per_launch"] * S / tj["sites_per_launch"]
+        ops = fp64_ops_per_site(plan)
+        out = {
+            "metric": "variant sites/sec (whole node), %d-member pedigree BN posterior" % n,
+            "value": value, "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d seeded synthetic sites per GPU, %d-member pedigree (3^%d = %d configs/site), "
+                                   "-method 1 BN posterior, all sites full enumeration" % (a.workload, S, n, n, 3 ** n),
+                       "sites_per_gpu": S, "global_sites": total_sites, "parallelism": "sites sharded x%d, no collective" % world,
+                       "plan": {k: plan[k] for k in ("L", "A", "J", "team_lanes", "teams_per_block", "block_threads",
+                                                     "lds_bytes", "blocks_per_cu")}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "bn_enum_kernel<%d>" % plan["L"], "kernel_ms": kernel_ms,
+                         "bytes_per_site": bytes_per_site,
+                         "read_GBps": S * (24 * n + 1) / (kernel_ms * 1e-3) / 1e9},
+            "fp64_valu": {"achieved": S * ops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TOPS,
+                          "unit": "Tops/s", "frac": S * ops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
+                          "ops_per_site": ops, "configs_per_s": S * 3 ** n / (kernel_ms * 1e-3)},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(ped, cfg, a.cpu_seconds, n)
+            out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,282 @@
+// capi.cpp — the C ABI of libfamseq_hip.so (see include/famseq_hip.h).
+//
+// Replaces the host driver the reference wraps around its kernel
+// (/root/reference/src/family.cu:1106-1705: per SITE 6 cudaMalloc, 5 H2D copies, one
+// launch, a 4096x3N D2H copy, a host reduction and 6 cudaFree).  Here the context owns
+// device memory, streams and pinned staging for its lifetime, a call moves a whole batch,
+// and nothing is reduced on the host.  There is no CPU compute path in this library.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bn_kernel.h"
+#include "famseq_hip.h"
+#include "plan.h"
+
+using namespace famseq;
+
+struct famseq_ctx {
+  famseq_model model{};
+  PlanOptions opt{};
+  Plan plan{};
+  KParams kp{};
+  bool plan_dirty = true;
+  int device = -1;
+  int n_cus = 0;
+  int blocks_per_cu = 0;
+  int64_t grid_override = 0;
+  int64_t chunk_sites = 0;
+  // device constants
+  uint32_t *d_img = nullptr;
+  double *d_tc = nullptr;
+  // staging for the host-buffer entry point: two slots so copies overlap compute
+  static constexpr int kSlots = 2;
+  hipStream_t stream[kSlots] = {nullptr, nullptr};
+  int64_t slot_sites = 0;
+  double *d_lk[kSlots] = {}, *d_post[kSlots] = {}, *d_single[kSlots] = {};
+  uint8_t *d_flags[kSlots] = {}, *d_status[kSlots] = {};
+  std::string err, json;
+};
+
+namespace {
+
+void set_err(char *err, size_t n, const std::string &msg) {
+  if (err && n) {
+    std::snprintf(err, n, "%s", msg.c_str());
+  }
+}
+
+int fail(famseq_ctx *c, int code, const std::string &msg) {
+  c->err = msg;
+  return code;
+}
+
+#define HIP_TRY(c, call)                                                                              \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail((c), FAMSEQ_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+void validate_model(const famseq_model &m) {
+  const int n = m.n_members;
+  if (n < 1 || n > FAMSEQ_MAX_MEMBERS) throw std::runtime_error("n_members must be 1..20");
+  for (int i = 0; i < n; ++i) {
+    const int mo = m.mother[i], fa = m.father[i];
+    if ((mo < 0) != (fa < 0)) throw std::runtime_error("member with exactly one known parent");
+    if (mo >= n || fa >= n) throw std::runtime_error("parent index out of range");
+  }
+}
+
+void free_slots(famseq_ctx *c) {
+  for (int s = 0; s < famseq_ctx::kSlots; ++s) {
+    if (c->d_lk[s]) (void)hipFree(c->d_lk[s]);
+    if (c->d_post[s]) (void)hipFree(c->d_post[s]);
+    if (c->d_single[s]) (void)hipFree(c->d_single[s]);
+    if (c->d_flags[s]) (void)hipFree(c->d_flags[s]);
+    if (c->d_status[s]) (void)hipFree(c->d_status[s]);
+    c->d_lk[s] = c->d_post[s] = c->d_single[s] = nullptr;
+    c->d_flags[s] = c->d_status[s] = nullptr;
+  }
+  c->slot_sites = 0;
+}
+
+// (Re)build the plan and, on a device ctx, upload its image and the factor tables.
+int refresh_plan(famseq_ctx *c) {
+  if (!c->plan_dirty) return 0;
+  try {
+    c->plan = build_plan(c->model, c->opt);
+  } catch (const std::exception &e) {
+    return fail(c, FAMSEQ_E_ARG, std::string("plan: ") + e.what());
+  }
+  c->kp = make_kparams(c->plan, c->model.lc);
+  if (c->device >= 0) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<uint32_t> img = c->plan.device_image();
+    for (int i = 0; i < c->plan.N; ++i)
+      img[c->kp.off_minfo + i] |= uint32_t(c->model.sequenced[i] ? 1 : 0) << 2;
+    if (c->d_img) (void)hipFree(c->d_img);
+    c->d_img = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_img), img.size() * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_img, img.data(), img.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    double tc[4 * 4 * 27];
+    build_factor_tables(c->model, tc);
+    if (!c->d_tc) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_tc), sizeof tc));
+    HIP_TRY(c, hipMemcpy(c->d_tc, tc, sizeof tc, hipMemcpyHostToDevice));
+    hipError_t e = hipSuccess;
+    c->blocks_per_cu = bn_enum_blocks_per_cu(c->plan, &e);
+    if (c->blocks_per_cu < 1)
+      return fail(c, FAMSEQ_E_HIP, std::string("occupancy query: ") + hipGetErrorString(e));
+  }
+  c->plan_dirty = false;
+  return 0;
+}
+
+int grid_for(const famseq_ctx *c, int64_t n_sites) {
+  const int64_t passes = (n_sites + c->plan.teams_per_block - 1) / c->plan.teams_per_block;
+  int64_t resident = c->grid_override > 0 ? c->grid_override : int64_t(c->n_cus) * c->blocks_per_cu;
+  return (int)std::max<int64_t>(1, std::min(passes, resident));
+}
+
+}  // namespace
+
+extern "C" int famseq_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" famseq_ctx *famseq_create(const famseq_model *model, int device_id, char *err, size_t errlen) {
+  if (!model) {
+    set_err(err, errlen, "model is NULL");
+    return nullptr;
+  }
+  famseq_ctx *c = new famseq_ctx;
+  c->model = *model;
+  try {
+    validate_model(c->model);
+  } catch (const std::exception &e) {
+    set_err(err, errlen, e.what());
+    delete c;
+    return nullptr;
+  }
+  if (device_id >= 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device_id >= n) {
+      set_err(err, errlen, "no usable HIP device " + std::to_string(device_id) + " (" +
+                               (e != hipSuccess ? hipGetErrorString(e) : "device_id out of range") + ")");
+      delete c;
+      return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
+      set_err(err, errlen, std::string("hipSetDevice: ") + hipGetErrorString(e));
+      delete c;
+      return nullptr;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      set_err(err, errlen, std::string("device is ") + prop.gcnArchName + ", this library only carries gfx950 code");
+      delete c;
+      return nullptr;
+    }
+    c->device = device_id;
+    c->n_cus = prop.multiProcessorCount;
+    for (int s = 0; s < famseq_ctx::kSlots; ++s)
+      if ((e = hipStreamCreateWithFlags(&c->stream[s], hipStreamNonBlocking)) != hipSuccess) {
+        set_err(err, errlen, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        famseq_destroy(c);
+        return nullptr;
+      }
+  }
+  if (refresh_plan(c) != 0) {
+    set_err(err, errlen, c->err);
+    famseq_destroy(c);
+    return nullptr;
+  }
+  return c;
+}
+
+extern "C" void famseq_destroy(famseq_ctx *c) {
+  if (!c) return;
+  if (c->device >= 0) {
+    (void)hipSetDevice(c->device);
+    free_slots(c);
+    if (c->d_img) (void)hipFree(c->d_img);
+    if (c->d_tc) (void)hipFree(c->d_tc);
+    for (int s = 0; s < famseq_ctx::kSlots; ++s)
+      if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
+  }
+  delete c;
+}
+
+extern "C" const char *famseq_last_error(famseq_ctx *c) { return c ? c->err.c_str() : "ctx is NULL"; }
+
+extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) {
+  if (!c || !key) return FAMSEQ_E_ARG;
+  const std::string k(key);
+  PlanOptions saved = c->opt;
+  if (k == "fixed_digits") c->opt.fixed_digits = (int)value;
+  else if (k == "low_members") c->opt.low_members = (int)value;
+  else if (k == "block_threads") c->opt.block_threads = (int)value;
+  else if (k == "grid_blocks") { c->grid_override = value; return 0; }
+  else if (k == "chunk_sites") { c->chunk_sites = value; free_slots(c); return 0; }
+  else return fail(c, FAMSEQ_E_ARG, "unknown option " + k);
+  c->plan_dirty = true;
+  const int rc = refresh_plan(c);
+  if (rc != 0) {  // keep the previous, working plan
+    c->opt = saved;
+    c->plan_dirty = true;
+    const std::string why = c->err;
+    (void)refresh_plan(c);
+    c->err = why;
+  }
+  return rc;
+}
+
+extern "C" const char *famseq_plan_json(famseq_ctx *c) {
+  if (!c) return "{}";
+  c->json = c->plan.json();
+  c->json.pop_back();
+  c->json += ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
+             ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + "}";
+  return c->json.c_str();
+}
+
+extern "C" int famseq_bn_batch_device(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags,
+                                      double *d_post, double *d_single, uint8_t *d_status, void *stream) {
+  if (!c) return FAMSEQ_E_ARG;
+  if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
+  if (n_sites < 0 || (n_sites > 0 && (!d_lk || !d_post))) return fail(c, FAMSEQ_E_ARG, "bad batch arguments");
+  if (n_sites == 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, launch_bn_enum(c->plan, c->kp, grid_for(c, n_sites), c->d_img, c->d_tc, n_sites, d_lk, d_flags, d_post,
+                            d_single, d_status, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int famseq_bn_batch(famseq_ctx *c, int64_t n_sites, const double *lk, const uint8_t *flags, double *post,
+                               double *post_single, uint8_t *status) {
+  if (!c) return FAMSEQ_E_ARG;
+  if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
+  if (n_sites < 0 || (n_sites > 0 && (!lk || !post))) return fail(c, FAMSEQ_E_ARG, "bad batch arguments");
+  if (n_sites == 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t row = size_t(3) * c->plan.N * sizeof(double);
+  int64_t chunk = c->chunk_sites > 0 ? c->chunk_sites : std::max<int64_t>(1, (int64_t(64) << 20) / int64_t(row));
+  chunk = std::min(chunk, n_sites);
+  if (c->slot_sites < chunk) {
+    free_slots(c);
+    for (int s = 0; s < famseq_ctx::kSlots; ++s) {
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_lk[s]), chunk * row));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_post[s]), chunk * row));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_single[s]), chunk * row));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_flags[s]), chunk));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_status[s]), chunk));
+    }
+    c->slot_sites = chunk;
+  }
+  int k = 0;
+  for (int64_t lo = 0; lo < n_sites; lo += chunk, ++k) {
+    const int s = k % famseq_ctx::kSlots;
+    const int64_t n = std::min(chunk, n_sites - lo);
+    hipStream_t st = c->stream[s];
+    HIP_TRY(c, hipStreamSynchronize(st));  // the slot's previous chunk has fully drained
+    HIP_TRY(c, hipMemcpyAsync(c->d_lk[s], lk + lo * 3 * c->plan.N, n * row, hipMemcpyHostToDevice, st));
+    if (flags) HIP_TRY(c, hipMemcpyAsync(c->d_flags[s], flags + lo, n, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, launch_bn_enum(c->plan, c->kp, grid_for(c, n), c->d_img, c->d_tc, n, c->d_lk[s],
+                              flags ? c->d_flags[s] : nullptr, c->d_post[s], post_single ? c->d_single[s] : nullptr,
+                              status ? c->d_status[s] : nullptr, st));
+    HIP_TRY(c, hipMemcpyAsync(post + lo * 3 * c->plan.N, c->d_post[s], n * row, hipMemcpyDeviceToHost, st));
+    if (post_single)
+      HIP_TRY(c, hipMemcpyAsync(post_single + lo * 3 * c->plan.N, c->d_single[s], n * row, hipMemcpyDeviceToHost, st));
+    if (status) HIP_TRY(c, hipMemcpyAsync(status + lo, c->d_status[s], n, hipMemcpyDeviceToHost, st));
+  }
+  for (int s = 0; s < famseq_ctx::kSlots; ++s) HIP_TRY(c, hipStreamSynchronize(c->stream[s]));
+  return 0;
+}

@@ -132,3 +132,72 @@ def write_vcf(path, names, pl, known, true_geno, first_site=0):
             for i in range(pl.shape[1]):
                 cols.append("%s:%d,%d,%d" % (gt[true_geno[s, i]], pl[s, i, 0], pl[s, i, 1], pl[s, i, 2]))
             f.write("\t".join(cols) + "\n")
+
+
+# --------------------------------------------------------------------------------------
+# The same generator with torch int64 arithmetic (wraps like uint64), so bench.py can
+# create the 10M-site batch directly in HBM.  Bit-identical to gen_sites (tested).
+# --------------------------------------------------------------------------------------
+def _s64(x):
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _lsr(z, k):
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def gen_batch_torch(mother, father, n_sites, config_no, first_site=0, device="cpu", chunk=1 << 20,
+                    out_lk=None, out_flags=None):
+    """-> (lk[float64 S,N,3], flags[uint8 S]) torch tensors on `device`."""
+    import torch
+
+    n = len(mother)
+    D = 2 + 4 * n
+    order = _topo(mother, father)
+    seed = SEED_BASE + config_no
+    g_, m1, m2 = _s64(int(GAMMA)), _s64(int(M1)), _s64(int(M2))
+    lut = torch.from_numpy(PL_LUT).to(device)
+    lk = out_lk if out_lk is not None else torch.empty((n_sites, n, 3), dtype=torch.float64, device=device)
+    flags = out_flags if out_flags is not None else torch.empty(n_sites, dtype=torch.uint8, device=device)
+    for lo in range(0, n_sites, chunk):
+        hi = min(n_sites, lo + chunk)
+        site = torch.arange(first_site + lo, first_site + hi, dtype=torch.int64, device=device)
+        base = site * D
+
+        def draw(k):
+            z = (base + (k + 1)) * g_ + _s64(seed)
+            z = (z ^ _lsr(z, 30)) * m1
+            z = (z ^ _lsr(z, 27)) * m2
+            return z ^ _lsr(z, 31)
+
+        def u01(z):
+            return _lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+        q = 0.01 + 0.49 * u01(draw(0))
+        g = [None] * n
+        for i in order:
+            u1, u2 = u01(draw(1 + 2 * i)), u01(draw(2 + 2 * i))
+            if mother[i] < 0:
+                g[i] = (u1 < q).to(torch.int64) + (u2 < q).to(torch.int64)
+            else:
+                gm, gf = g[mother[i]], g[father[i]]
+                am = torch.where(gm == 1, u1 < 0.5, gm == 2)
+                af = torch.where(gf == 1, u2 < 0.5, gf == 2)
+                g[i] = am.to(torch.int64) + af.to(torch.int64)
+        flags[lo:hi] = (u01(draw(2 * n + 1)) < 0.10).to(torch.uint8)
+        zero = torch.zeros(hi - lo, dtype=torch.int64, device=device)
+        for i in range(n):
+            r1 = _lsr(draw(2 * n + 2 + 2 * i), 33)
+            r2 = _lsr(draw(2 * n + 3 + 2 * i), 33)
+            a1 = 3 + r1 % 88
+            a2 = 3 + r2 % 88
+            far = torch.clamp(a1 + 10 + r2 % 156, max=255)
+            t = g[i]
+            p0 = torch.where(t == 0, zero, torch.where(t == 1, a1, far))
+            p1 = torch.where(t == 1, zero, a1)
+            p2 = torch.where(t == 2, zero, torch.where(t == 1, a2, far))
+            lk[lo:hi, i, 0] = lut[p0]
+            lk[lo:hi, i, 1] = lut[p1]
+            lk[lo:hi, i, 2] = lut[p2]
+    return lk, flags

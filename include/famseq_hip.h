@@ -1,0 +1,132 @@
+/*
+ * famseq_hip.h — C ABI of libfamseq_hip.so: the MI355X (gfx950) implementation of
+ * FamSeq's `-method 1` Bayesian-network pedigree genotype posterior.
+ *
+ * Boundary being replaced (all cites into /root/reference/src):
+ *   the per-site operator   bool family::calPostProbBN(bool Known,int chrType)  family.h:375,
+ *                           family.cpp:750-1124 (CUDA twin family.cu:974-2305)
+ *   fed by                  bool family::set_LK(const dMatrix<double>&)          family.h:344, family.cpp:698-748
+ *   and drained by          get_postProb / get_postProbSingle / get_postRlt      family.h:262,265,308
+ *   called from             file.cpp:595->607->680-682, :833->845->918-920, :1743->1751->1804-1806
+ * The reference crosses host->device once per site (6 cudaMalloc + 5 H2D + 1 launch
+ * + 1 D2H per site, family.cu:1152-1703).  This ABI re-cuts the same operator as a
+ * BATCH of sites per call: plain pointers and sizes, no C++ or torch types.
+ *
+ * Data layout (both directions): [n_sites][n_members][3] fp64, row-major, members in
+ * PED order, genotype order RR,RA,AA — i.e. dMatrix<double> N x 3 (dMatrix.h:141-151)
+ * repeated per site.  flags[s]: bit0 = Known (ID != "."), bit1 = chrX (file.cpp:476-486).
+ *
+ * status[s] (replaces the bool return + flagPB/flagPBS, family.cpp:752-763, :946-949):
+ *   0     ok, full enumeration
+ *   0x80  ok, took the -LRC single-sample shortcut (family.cpp:767-878)
+ *   1     calPostProbSingle failed: a lk*prior row sum <= 0 (family.cpp:1437); post and
+ *         post_single are NaN-filled — the caller prints `:NA:NA:NA` (file.cpp:607-620)
+ *   2     BN row sum <= 0 (family.cpp:946/:1111); post is NaN-filled, post_single valid
+ *
+ * There is NO CPU fallback: every compute entry point fails (negative return, message
+ * in famseq_last_error) when no gfx950 device is usable.
+ */
+#ifndef FAMSEQ_HIP_H_
+#define FAMSEQ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FAMSEQ_MAX_MEMBERS 20 /* reference CUDA limit: geno[20], pTmp[60] (family.cu:771-772) */
+
+#define FAMSEQ_ST_OK 0
+#define FAMSEQ_ST_SINGLE_FAIL 1
+#define FAMSEQ_ST_BN_FAIL 2
+#define FAMSEQ_ST_SHORTCUT 0x80
+
+#define FAMSEQ_FLAG_KNOWN 1
+#define FAMSEQ_FLAG_CHRX 2
+
+/* error codes (negative returns) */
+#define FAMSEQ_E_ARG (-1)      /* bad argument / model rejected */
+#define FAMSEQ_E_NODEVICE (-2) /* no usable gfx950 device, or ctx created without one */
+#define FAMSEQ_E_HIP (-3)      /* HIP runtime error, see famseq_last_error */
+#define FAMSEQ_E_PED_HALF (-10) /* member with exactly one known parent (family.cpp:319-323) */
+#define FAMSEQ_E_PED_SEX (-11)  /* mother not female / father not male (family.cpp:204-219) */
+
+/* Everything `family` holds after setFam()+init() that the path reads
+ * (file.cpp:1888-1927; family.cpp:78-127, 221-238). */
+typedef struct {
+  int32_t n_members;                     /* numInd, 1..FAMSEQ_MAX_MEMBERS */
+  int32_t mother[FAMSEQ_MAX_MEMBERS];    /* parent[i][0] or -1            family.cpp:329 */
+  int32_t father[FAMSEQ_MAX_MEMBERS];    /* parent[i][1] or -1            family.cpp:330 */
+  int32_t gender[FAMSEQ_MAX_MEMBERS];    /* 1 = male, anything else is treated as female (family.cpp:1054) */
+  uint8_t sequenced[FAMSEQ_MAX_MEMBERS]; /* 1 if the member is in mapV2P (has a VCF/LK column); the
+                                            shortcut vote runs over these only (family.cpp:768-771) */
+  double pcp2[27];   /* autosome   [child*9 + mother*3 + father]  family.cpp:447-550 */
+  double pcp2Xf[27]; /* chrX daughter                             family.cpp:383-416 */
+  double pcp2Xm[27]; /* chrX son                                  family.cpp:418-445 */
+  double genoProbN[3], genoProbK[3], genoProbXN[3], genoProbXK[3]; /* family.cpp:91-109 */
+  double lc;         /* m_lc, -LRC                                family.cpp:253-257 */
+} famseq_model;
+
+typedef struct famseq_ctx famseq_ctx;
+
+/* ---- one-time model setup (replaces family ctor + init()) ---------------- */
+
+/* calPCP2S / calPCP2Xf / calPCP2Xm for mutation rate `mrate`, bit-faithful to the
+ * reference's accumulation order.  Each output is 27 doubles. */
+void famseq_transmission_tables(double mrate, double *pcp2, double *pcp2Xf, double *pcp2Xm);
+
+/* PED columns -> model: default priors, tables for `mrate`, setRelation, checkPed.
+ * `sequenced` may be NULL (all sequenced).  Returns 0 or FAMSEQ_E_*. */
+int famseq_model_init(famseq_model *m, int32_t n_members, const int32_t *id, const int32_t *mother_id,
+                      const int32_t *father_id, const int32_t *gender, const uint8_t *sequenced,
+                      double mrate, double lc);
+
+/* ---- context -------------------------------------------------------------- */
+
+int famseq_device_count(void); /* visible HIP devices; 0 when there is none */
+
+/* Validates the model, builds the enumeration plan and (device_id >= 0) binds one GPU:
+ * uploads constants, creates streams and staging buffers.  One ctx = one device = one
+ * caller thread (multi-GPU = one process/ctx per device, sites sharded by the caller).
+ * device_id < 0 builds a plan-only ctx (for inspection; compute calls return
+ * FAMSEQ_E_NODEVICE).  On failure returns NULL with a message in err. */
+famseq_ctx *famseq_create(const famseq_model *model, int device_id, char *err, size_t errlen);
+void famseq_destroy(famseq_ctx *ctx);
+const char *famseq_last_error(famseq_ctx *ctx);
+
+/* Integer knobs; must be set before the first batch call.  Keys:
+ *   "fixed_digits"  A: high members mapped onto lanes (team = 3^A lanes), 0..6
+ *   "low_members"   L: childless members enumerated in the unrolled register loop, 1..5
+ *   "block_threads" workgroup size (multiple of 64, <= 1024)
+ *   "grid_blocks"   persistent grid size (0 = auto: CUs x resident blocks)
+ *   "chunk_sites"   host-staging chunk of famseq_bn_batch (0 = auto)
+ * Returns 0 or FAMSEQ_E_ARG. */
+int famseq_set_option(famseq_ctx *ctx, const char *key, int64_t value);
+
+/* JSON description of the plan and launch geometry (valid until the next call on ctx). */
+const char *famseq_plan_json(famseq_ctx *ctx);
+
+/* ---- the operator ---------------------------------------------------------- */
+
+/* Host buffers (pageable or pinned).  Blocking.  Stages through pinned memory in chunks
+ * with H2D / kernel / D2H overlapped on separate HIP streams.  post_single and status may
+ * be NULL.  Returns 0 or a negative error. */
+int famseq_bn_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, const uint8_t *flags,
+                    double *post, double *post_single, uint8_t *status);
+
+/* Device buffers already resident in HBM on ctx's device.  Enqueues on `stream`
+ * (a hipStream_t; NULL = the default stream) and returns without synchronising.
+ * d_post_single and d_status may be NULL. */
+int famseq_bn_batch_device(famseq_ctx *ctx, int64_t n_sites, const double *d_lk, const uint8_t *d_flags,
+                           double *d_post, double *d_post_single, uint8_t *d_status, void *stream);
+
+/* get_postRlt (family.cpp:636-665) for one N x 3 posterior row block: arg-max with
+ * strict '<' starting from -1, so ties resolve to the lowest genotype. */
+void famseq_call_genotypes(const double *post, int64_t n_rows, int8_t *geno);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAMSEQ_HIP_H_ */

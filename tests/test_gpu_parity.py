@@ -1,0 +1,176 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference fixtures.
+
+Bars (BASELINE.json north_star: posteriors to 1e-6 relative):
+  * status byte and single posterior: bit-exact (same arithmetic order, fp64, no FMA);
+  * BN posterior: rtol 1e-9 here (the enumeration only re-orders an fp64 sum of
+    non-negative terms, so agreement is ~1e-15; 1e-9 leaves margin, 1e-6 is the bar)."""
+import numpy as np
+import pytest
+
+import famseq_amd as fs
+import oracle
+from _cases import load_cases
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+CASES = load_cases()
+BY = {c.name: c for c in CASES}
+
+
+def check(c, post, single, st, ref=None):
+    rpost, rsingle, rst = ref if ref is not None else (c.post, c.single, c.status)
+    assert np.array_equal(st, rst)
+    ok, s_ok = (rst & 3) == 0, (rst & 3) != 1
+    assert np.array_equal(single[s_ok].view(np.uint64), rsingle[s_ok].view(np.uint64))
+    np.testing.assert_allclose(post[ok], rpost[ok], rtol=RTOL, atol=0)
+    assert np.all(np.isnan(post[~ok])) and np.all(np.isnan(single[~s_ok]))
+    short = (rst & 0x80) != 0
+    assert np.array_equal(post[short].view(np.uint64), rpost[short].view(np.uint64))
+
+
+@pytest.mark.parametrize("c", CASES, ids=repr)
+def test_fixture_parity(c):
+    """Every compiled-reference fixture: 72 VCF site results, 600 LK rows, synthetic
+    autosome/chrX/custom-constant batches, failure and shortcut-boundary probes."""
+    ctx = fs.Context(fs.make_model(c.pedigree(), **c.consts))
+    check(c, *ctx.bn_batch(c.lk, c.flags))
+    ctx.close()
+
+
+TILINGS = [dict(fixed_digits=0), dict(fixed_digits=1), dict(fixed_digits=2, low_members=1), dict(low_members=2),
+           dict(fixed_digits=3, low_members=2), dict(fixed_digits=6), dict(block_threads=512), dict(block_threads=64)]
+
+
+@pytest.mark.parametrize("name", ["bn_synth:ped10", "bn_synth:ped10_x", "bn_vcf:fam01", "bn_synth:ped5", "bn_synth:chain7", "bn_synth:quad_mu0"])
+@pytest.mark.parametrize("opt", TILINGS, ids=lambda o: ",".join("%s%d" % (k[0], v) for k, v in o.items()))
+def test_every_tiling_gives_the_same_answer(name, opt):
+    """The result must not depend on how the 3^N space is cut into lanes/steps/low loop
+    (exercises multi-team workgroups, 1..3 nested iter levels, 729-lane teams)."""
+    c = BY[name]
+    try:
+        ctx = fs.Context(fs.make_model(c.pedigree(), **c.consts), **opt)
+    except fs.FamseqError as e:
+        pytest.skip("tiling not applicable: %s" % e)
+    check(c, *ctx.bn_batch(c.lk, c.flags))
+    ctx.close()
+
+
+def test_null_optional_outputs_and_empty_batch():
+    c = BY["bn_synth:ped5"]
+    ctx = fs.Context(fs.make_model(c.pedigree()))
+    post, single, st = ctx.bn_batch(c.lk, None, want_single=False, want_status=False)
+    assert single is None and st is None
+    ref = ctx.bn_batch(c.lk, np.zeros(len(c.lk), np.uint8))
+    assert np.array_equal(post, ref[0])
+    p0, _, s0 = ctx.bn_batch(np.zeros((0, 5, 3)), np.zeros(0, np.uint8))
+    assert p0.shape == (0, 5, 3) and s0.shape == (0,)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n_sites", [1, 27, 28, 29, 57, 1000])
+def test_ragged_batch_sizes(n_sites):
+    """Batch sizes around the 28-sites-per-workgroup tiling of ped5, chunked staging included."""
+    c = BY["bn_synth:ped5"]
+    reps = -(-n_sites // len(c.lk))
+    lk = np.tile(c.lk, (reps, 1, 1))[:n_sites]
+    flags = np.tile(c.flags, reps)[:n_sites]
+    ref = tuple(np.tile(a, (reps,) + (1,) * (a.ndim - 1))[:n_sites] for a in (c.post, c.single, c.status))
+    ctx = fs.Context(fs.make_model(c.pedigree()), chunk_sites=400)
+    check(c, *ctx.bn_batch(lk, flags), ref=ref)
+    ctx.close()
+
+
+def test_family_mirror_reads_like_the_reference():
+    """set_LK / calPostProbBN / get_postProb / get_postRlt on fam04 (PED order != VCF order)."""
+    c = BY["bn_vcf:fam04"]
+    ped = fs.read_ped(fs.os.path.join(fs.HERE, "..", "tests", "golden", "testdata", "fam04.ped"))
+    fam = fs.Family(ped)
+    names = ["ind%02d" % k for k in range(1, 16)]
+    fam.set_mapV2P([ped.names.index(n) if n in ped.names else -1 for n in names])
+    assert fam.get_numInd() == 6 and fam.get_realNumInd() == 2
+    assert fam.set_LK(c.lk)
+    ok = fam.calPostProbBN((c.flags & 1) != 0, (c.flags >> 1) & 1)
+    assert ok.all()
+    seq = [ped.names.index("ind08"), ped.names.index("ind09")]  # VCF column order
+    np.testing.assert_allclose(fam.get_postProb(), c.post[:, seq, :], rtol=RTOL)
+    assert np.array_equal(fam.get_postProbSingle(), c.single[:, seq, :])
+    want = np.array([[oracle.argmax3(r) for r in site] for site in c.post[:, seq, :]])
+    assert np.array_equal(fam.get_postRlt(), want)
+    assert not fam.set_LK(np.ones((3, 5, 3)))
+
+
+def test_device_pointer_entry_matches_host_entry():
+    torch = pytest.importorskip("torch")
+    c = BY["bn_synth:ped10"]
+    ctx = fs.Context(fs.make_model(c.pedigree()))
+    dev = torch.device("cuda:0")
+    lk = torch.from_numpy(c.lk).to(dev)
+    fl = torch.from_numpy(c.flags).to(dev)
+    post, single = torch.empty_like(lk), torch.empty_like(lk)
+    st = torch.empty(len(c.lk), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    ctx.bn_batch_device(len(c.lk), lk.data_ptr(), fl.data_ptr(), post.data_ptr(), single.data_ptr(), st.data_ptr(),
+                        stream.cuda_stream)
+    stream.synchronize()
+    host = ctx.bn_batch(c.lk, c.flags)
+    assert np.array_equal(post.cpu().numpy(), host[0]) and np.array_equal(single.cpu().numpy(), host[1])
+    assert np.array_equal(st.cpu().numpy(), host[2])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,cfg,n_sites", [("ped5", 1, 200_000), ("ped10", 2, 20_000)])
+def test_full_size_properties(name, cfg, n_sites):
+    """Size-independent properties on large seeded batches (BASELINE configs' shape):
+    rows are distributions, the run is bit-reproducible, the answer does not depend on
+    batch position or on how the batch is sharded, and a sampled subset matches the oracle."""
+    ped = fs.synthetic_pedigree(name)
+    mo, fa = ped.relations()
+    lk, flags = fs.synth.gen_batch(mo, fa, n_sites, cfg)
+    ctx = fs.Context(fs.make_model(ped))
+    post, single, st = ctx.bn_batch(lk, flags)
+    assert np.all(st == 0)  # generator guarantees no shortcut, no failure
+    assert np.all(post >= 0) and np.allclose(post.sum(axis=2), 1.0, rtol=0, atol=1e-12)
+    again = ctx.bn_batch(lk, flags)
+    assert np.array_equal(again[0], post) and np.array_equal(again[1], single)
+    perm = np.random.RandomState(3).permutation(n_sites)
+    p2 = ctx.bn_batch(lk[perm], flags[perm])[0]
+    assert np.array_equal(p2, post[perm])
+    cut = n_sites // 3 + 1
+    halves = [ctx.bn_batch(lk[a:b], flags[a:b])[0] for a, b in ((0, cut), (cut, n_sites))]
+    assert np.array_equal(np.concatenate(halves), post)
+    idx = np.random.RandomState(5).choice(n_sites, 64, replace=False)
+    o = oracle.OracleModel(ped.ids, ped.mids, ped.fids, ped.genders)
+    ref = o.bn_batch(lk[idx], flags[idx], threads=4)
+    np.testing.assert_allclose(post[idx], ref[0], rtol=RTOL)
+    assert np.array_equal(single[idx], ref[1])
+    ctx.close()
+
+
+def test_deep_enumeration_ped15_and_max_members():
+    """3^15 configurations per site (BASELINE config 5 shape) and a 13-member chain with a
+    single childless member (two nested iter levels); one or two sites against the oracle."""
+    ped = fs.synthetic_pedigree("ped15")
+    mo, fa = ped.relations()
+    lk, flags = fs.synth.gen_batch(mo, fa, 2, 5)
+    ctx = fs.Context(fs.make_model(ped))
+    post, single, st = ctx.bn_batch(lk, flags)
+    ref = oracle.OracleModel(ped.ids, ped.mids, ped.fids, ped.genders).bn_batch(lk, flags, threads=2)
+    assert np.array_equal(st, ref[2])
+    np.testing.assert_allclose(post, ref[0], rtol=RTOL)
+    ctx.close()
+    ids = list(range(1, 14))
+    mids = [0, 0, 2, 0, 4, 0, 6, 0, 8, 0, 10, 0, 12]
+    fids = [0, 0, 1, 0, 3, 0, 5, 0, 7, 0, 9, 0, 11]
+    gen = [1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 2]
+    chain = fs.Pedigree(ids, mids, fids, gen, ["s%d" % i for i in ids])
+    mo, fa = chain.relations()
+    lk, flags = fs.synth.gen_batch(mo, fa, 3, 41)
+    flags[1] |= 2
+    ctx = fs.Context(fs.make_model(chain))
+    assert ctx.plan()["jlevels"] == 2
+    post, single, st = ctx.bn_batch(lk, flags)
+    ref = oracle.OracleModel(ids, mids, fids, gen).bn_batch(lk, flags, threads=3)
+    assert np.array_equal(st, ref[2])
+    np.testing.assert_allclose(post, ref[0], rtol=RTOL)
+    ctx.close()
