@@ -10,7 +10,9 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iincl
 SRCS := $(CSRC)/bn_kernel.hip $(CSRC)/capi.cpp $(CSRC)/plan.cpp $(CSRC)/model.cpp
 OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 
-all: $(LIB)
+CLI := bin/FamSeq
+
+all: $(LIB) $(CLI)
 
 build/%.o: $(CSRC)/% $(wildcard $(CSRC)/*.h) include/famseq_hip.h
 	@mkdir -p build
@@ -31,10 +33,16 @@ $(LIB): $(OBJS) build/stub/libamdhip64.so
 	g++ -shared -fPIC -o $@ $(OBJS) -Wl,--no-as-needed -Lbuild/stub -lamdhip64 -Wl,--as-needed \
 	    -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
 
+# FamSeq-compatible command line (host C++ only; talks to the GPU through the C ABI)
+$(CLI): $(CSRC)/host/famseq_cli.cpp include/famseq_hip.h $(LIB)
+	@mkdir -p bin
+	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ $(CSRC)/host/famseq_cli.cpp -Lfamseq_amd/lib -lfamseq_hip \
+	    -Wl,-rpath,'$$ORIGIN/../famseq_amd/lib' -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
+
 oracle:
 	$(MAKE) -C oracle all $(if $(wildcard /root/reference/src/family.cpp),ref,)
 
 clean:
-	rm -rf build famseq_amd/lib
+	rm -rf build famseq_amd/lib bin
 
 .PHONY: all oracle clean

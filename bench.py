@@ -50,10 +50,10 @@ def parse():
 
 
 def fp64_ops_per_site(plan):
-    """fp64 operations the kernel executes per site in the enumeration (low tree only:
-    8 per node, (3^L - 1)/2 nodes per lane step), see DESIGN.md."""
+    """fp64 instructions the low tree executes per site: one FMA per configuration at the leaf
+    level plus a multiply and an FMA per internal edge (3^L + 2*(3^L - 3)/2 per lane step)."""
     L, A, J = plan["L"], plan["A"], plan["J"]
-    return 8 * (3 ** L - 1) // 2 * 3 ** (A + J)
+    return (3 ** L + (3 ** L - 3)) * 3 ** (A + J)
 
 
 def host_cores():

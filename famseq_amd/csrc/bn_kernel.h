@@ -13,7 +13,7 @@ namespace famseq {
 // Scalars the kernel needs; passed by value (kernarg segment -> SGPRs).
 struct KParams {
   int N, L, A, J;
-  int team_lanes, tpb, nA, nB, n_slots;
+  int team_lanes, tpb, nA, nB, n_slots, row_stride;
   int jn0, jn1, jn2, jd0, jd1, jd2, jlevels;
   int cols, parts;
   int off_joff, off_jdig, off_minfo;  // word offsets into the plan image

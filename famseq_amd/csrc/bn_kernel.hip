@@ -9,19 +9,20 @@
 // decodes N base-3 digits per configuration, keeps 3N partial sums per thread in scratch
 // and reduces 4096 partials on the host.  None of that is reused here.  This kernel:
 //   * owns one site per TEAM of 3^A lanes (a workgroup holds one or more teams),
-//   * never decodes a configuration: lane digits are baked into a per-lane offset table
-//     (LDS), iterated digits into per-step scalar offsets, low digits into the unrolled
-//     register loop (see plan.h),
-//   * shares prefix products down the low-member tree (~4 fp64 ops per configuration
-//     instead of 3N+1) and accumulates marginals hierarchically,
+//   * never decodes a configuration: lane digits are baked into a per-lane row of packed byte
+//     offsets (LDS), iterated digits into per-step records fetched with scalar loads, low
+//     digits into the unrolled register tree (see plan.h),
+//   * materialises every one of the 3^N joint weights with exactly one fp64 FMA (the leaf
+//     level of the tree) and gives every other member its marginal from block sums,
 //   * reduces across lanes through LDS in a fixed order (bit-reproducible run to run).
-// All arithmetic is fp64, FMA contraction off (the single posterior and the shortcut vote
-// are bit-identical to the CPU reference; the enumeration differs only by summation order).
+// All arithmetic is fp64; FMA contraction is off and FMAs appear only where written (the
+// single posterior and the shortcut vote are bit-identical to the CPU reference; the
+// enumeration differs from it only by summation order, ~1e-15 relative).
 //
 // LDS per workgroup (byte offsets in KParams):
 //   tc       [4 flag combos][4 kinds][27]  factor tables: prior at [9g] for founders,
 //                                           transmission table [9g+3gm+gf] for children
-//   laneoff  [n_slots][3^A] u32             packed (lk index << 16 | table index)
+//   laneoff  [3^A][row_stride] u32          lane t's packed offsets, one dword per plan entry
 //   lk       [teams][N][3]                  this pass's likelihood rows
 //   flags    [teams][4] + member info [N]
 //   red      [cols][block_threads]          per-lane results (column-major: conflict-free)
@@ -38,41 +39,39 @@ namespace famseq {
 
 namespace {
 
-constexpr int kTab = kIterTab;
+constexpr int kMaxList = FAMSEQ_MAX_MEMBERS;  // static bound of the A- and B-list loops
 
 // ---- the unrolled low-member tree ------------------------------------------------------
-// Level K multiplies the running prefix by member K's three factors; the innermost level
-// materialises the weight of each of the 3^L configurations.  Returns the subtree total;
-// lb[K][g] accumulates member K's marginal.
-// Instruction order matters here: left alone, hipcc hoists all 3^L products ahead of the
-// additions and spills them to scratch.  PIN() is an empty asm that takes a value "in/out":
-// volatile asms keep their program order, so the products of one leaf cannot be issued
-// before the additions of the previous leaf have consumed theirs.  It emits no instruction.
-#define FAMSEQ_PIN1(a) asm volatile("" : "+v"(a))
+// For fixed high digits the low members are independent 3-vectors v[k][.].  Level K owns a
+// prefix P (product down to level K-1) and hands P*v[K][g] to level K+1.  The leaf level forms
+// the weight of each of the 3^L configurations inside one FMA and adds it to the leaf member's
+// marginal.  The other members' marginals need the sum of a whole subtree, which for
+// independent members is P*v[K][g]*R[K] with R[K] = prod_{k>K} (v[k][0]+v[k][1]+v[k][2]).
+// Cost: 3^L FMAs at the leaves + 2*(3^L-3)/2 ops above = ~2 fp64 instructions per configuration.
+//
+// Instruction order matters: left alone, hipcc hoists the products of the whole unrolled tree
+// ahead of their uses and spills them to scratch.  PIN is an empty asm that takes a value
+// "in/out"; volatile asms keep program order, so work of one leaf cannot be issued before the
+// previous leaf has consumed its operands.  It emits no instruction.
+#define FAMSEQ_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #define FAMSEQ_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 template <int K, int L>
-__device__ __forceinline__ double low_tree(double prefix, const double (&v)[L][3], double (&lb)[L][3]) {
+__device__ __forceinline__ void low_tree(double prefix, const double (&v)[L][3], const double (&R)[L],
+                                         double (&lb)[L][3]) {
   if constexpr (K == L - 1) {
-    FAMSEQ_PIN1(prefix);
-    const double w0 = prefix * v[K][0];
-    const double w1 = prefix * v[K][1];
-    const double w2 = prefix * v[K][2];
-    lb[K][0] += w0;
-    lb[K][1] += w1;
-    lb[K][2] += w2;
-    double sub = (w0 + w1) + w2;
-    FAMSEQ_PIN4(lb[K][0], lb[K][1], lb[K][2], sub);
-    return sub;
+    lb[K][0] = __builtin_fma(prefix, v[K][0], lb[K][0]);
+    lb[K][1] = __builtin_fma(prefix, v[K][1], lb[K][1]);
+    lb[K][2] = __builtin_fma(prefix, v[K][2], lb[K][2]);
+    FAMSEQ_PIN4(lb[K][0], lb[K][1], lb[K][2], prefix);  // prefix dies here: no copy is made
   } else {
-    const double s0 = low_tree<K + 1, L>(prefix * v[K][0], v, lb);
-    const double s1 = low_tree<K + 1, L>(prefix * v[K][1], v, lb);
-    const double s2 = low_tree<K + 1, L>(prefix * v[K][2], v, lb);
-    lb[K][0] += s0;
-    lb[K][1] += s1;
-    lb[K][2] += s2;
-    double sub = (s0 + s1) + s2;
-    FAMSEQ_PIN4(lb[K][0], lb[K][1], lb[K][2], sub);
-    return sub;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      double pg = prefix * v[K][g];
+      lb[K][g] = __builtin_fma(pg, R[K], lb[K][g]);
+      FAMSEQ_PIN2(pg, lb[K][g]);  // both issued before the subtree below, which alone uses pg
+      low_tree<K + 1, L>(pg, v, R, lb);
+      FAMSEQ_PIN2(prefix, lb[K][g]);  // the next product waits for this subtree
+    }
   }
 }
 
@@ -82,8 +81,50 @@ __device__ __forceinline__ int ipow3(int e) {
   return r;
 }
 
+__device__ __forceinline__ double lds_f64(const unsigned char *base, uint32_t byte_off) {
+  return *reinterpret_cast<const double *>(base + byte_off);
+}
+
+// One step record = kStepSlots packed dwords, fetched with scalar loads (uniform address).
+struct StepRec {
+  uint32_t w[kStepSlots];
+};
+__device__ __forceinline__ void load_step(StepRec &r, const uint32_t *__restrict__ p) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < kStepSlots / 4; ++i) {
+    const uint4 x = q[i];
+    r.w[4 * i + 0] = x.x;
+    r.w[4 * i + 1] = x.y;
+    r.w[4 * i + 2] = x.z;
+    r.w[4 * i + 3] = x.w;
+  }
+}
+
+// low factors v[k][g] = T[.. + 9g] * lk[k][g] for the lane's (and step's) parent digits
 template <int L>
-__global__ __launch_bounds__(1024) void bn_enum_kernel(const KParams P, const uint32_t *__restrict__ img,
+__device__ __forceinline__ void load_low(double (&v)[L][3], double (&R)[L], double &Sall, const uint32_t *rowL,
+                                         const StepRec *rec, const unsigned char *tcf, const unsigned char *lkT) {
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+    uint32_t pk = rowL[k];
+    if (rec) pk += rec->w[k];
+    const uint32_t to = pk & 0xffffu, lo = pk >> 16;
+    v[k][0] = lds_f64(tcf, to) * lds_f64(lkT, lo);
+    v[k][1] = lds_f64(tcf, to + 72) * lds_f64(lkT, lo + 8);
+    v[k][2] = lds_f64(tcf, to + 144) * lds_f64(lkT, lo + 16);
+  }
+  double run = 1.0;
+#pragma unroll
+  for (int k = L - 1; k >= 0; --k) {
+    R[k] = run;
+    run = run * ((v[k][0] + v[k][1]) + v[k][2]);
+  }
+  Sall = run;
+}
+
+template <int L, bool LOWINV>
+__global__ __launch_bounds__(768) void bn_enum_kernel(const KParams P, const uint32_t *__restrict__ img,
                                                        const double *__restrict__ tc_g, const long n_sites,
                                                        const double *__restrict__ lk_g,
                                                        const uint8_t *__restrict__ flags_g, double *__restrict__ post_g,
@@ -106,14 +147,26 @@ __global__ __launch_bounds__(1024) void bn_enum_kernel(const KParams P, const ui
 
   // ---- once per workgroup: constants into LDS
   for (int i = tid; i < 4 * 4 * 27; i += BT) s_tc[i] = tc_g[i];
-  for (int i = tid; i < P.n_slots * TL; i += BT) s_lo[i] = img[i];
+  for (int i = tid; i < P.row_stride * TL; i += BT) s_lo[i] = img[i];
   for (int i = tid; i < N; i += BT) s_minfo[i] = (int)img[P.off_minfo + i];
   const int team = tid / TL;
   const int t = tid - team * TL;
   const double kNaN = __builtin_nan("");
+  // this lane's row of packed offsets: A-list entries, then the L low members, then the B list
+  const uint32_t *rowA = s_lo + (team < tpb ? t : 0) * P.row_stride;
+  const uint32_t *rowL = rowA + P.nA;
+  const uint32_t *rowB = rowL + L;
   __syncthreads();
 
-  for (long site0 = (long)blockIdx.x * tpb; site0 < n_sites; site0 += (long)gridDim.x * tpb) {
+  // Contiguous passes per workgroup: neighbouring sites share 128-byte lines, so keeping them
+  // on one CU/XCD avoids fetching those lines into two L2s.
+  const long passes = (n_sites + tpb - 1) / tpb;
+  const long per_wg = (passes + gridDim.x - 1) / gridDim.x;
+  const long pass_lo = (long)blockIdx.x * per_wg;
+  const long pass_hi = pass_lo + per_wg < passes ? pass_lo + per_wg : passes;
+
+  for (long pass = pass_lo; pass < pass_hi; ++pass) {
+    const long site0 = pass * tpb;
     const long left = n_sites - site0;
     const int nteam = left < tpb ? (int)left : tpb;
     const int nel = nteam * W3;
@@ -169,58 +222,61 @@ __global__ __launch_bounds__(1024) void bn_enum_kernel(const KParams P, const ui
     // digits spell t, for every iterated combination and all 3^L low combinations.
     const bool run = team < nteam && s_fl[4 * team + 1] != 0 && s_fl[4 * team + 2] == 0;
     if (run) {
-      const double *lkT = s_lk + team * W3;
-      const double *tcf = s_tc + s_fl[4 * team] * 108;
-      const uint32_t *lo = s_lo + t;
-      const int nAB = P.nA + P.nB;
+      const unsigned char *lkT = reinterpret_cast<const unsigned char *>(s_lk + team * W3);
+      const unsigned char *tcf = reinterpret_cast<const unsigned char *>(s_tc + s_fl[4 * team] * 108);
       double pA = 10000000;  // family.cpp:911
-      for (int s = 0; s < P.nA; ++s) {
-        const uint32_t pk = lo[s * TL];
-        pA = pA * (tcf[pk & 0xffffu] * lkT[pk >> 16]);
-      }
-      double lb[L][3];
+#pragma unroll
+      for (int s = 0; s < kMaxList; ++s)
+        if (s < P.nA) {
+          const uint32_t pk = rowA[s];
+          pA = pA * (lds_f64(tcf, pk & 0xffffu) * lds_f64(lkT, pk >> 16));
+        }
+      double lb[L][3], v[L][3], R[L], Sall;
 #pragma unroll
       for (int k = 0; k < L; ++k) lb[k][0] = lb[k][1] = lb[k][2] = 0;
+      if (LOWINV) load_low<L>(v, R, Sall, rowL, nullptr, tcf, lkT);
       double total = 0;
       for (int c = 3 * L; c < 3 * L + 3 * P.J; ++c) s_red[c * BT + tid] = 0;
       const bool deep = P.jlevels > 1;
+      const bool stepped = P.J > 0;
       for (int j2 = 0; j2 < P.jn2; ++j2) {
         double sub2 = 0;
         for (int j1 = 0; j1 < P.jn1; ++j1) {
           double sub1 = 0;
           for (int j0 = 0; j0 < P.jn0; ++j0) {
-            const uint32_t *jo0 = joff + j0;
-            const uint32_t *jo1 = joff + (size_t)P.n_slots * kTab + j1;
-            const uint32_t *jo2 = joff + (size_t)2 * P.n_slots * kTab + j2;
+            StepRec rec;
             double pj = pA;
-            for (int s = P.nA; s < nAB; ++s) {
-              uint32_t pk = lo[s * TL] + jo0[s * kTab];
-              if (deep) pk += jo1[s * kTab] + jo2[s * kTab];
-              pj = pj * (tcf[pk & 0xffffu] * lkT[pk >> 16]);
-            }
-            double v[L][3];
+            if (stepped) {
+              load_step(rec, joff + (size_t)j0 * kStepSlots);
+              if (deep) {
+                StepRec r1, r2;
+                load_step(r1, joff + ((size_t)kIterTab + j1) * kStepSlots);
+                load_step(r2, joff + ((size_t)2 * kIterTab + j2) * kStepSlots);
 #pragma unroll
-            for (int k = 0; k < L; ++k) {
-              const int s = nAB + k;
-              uint32_t pk = lo[s * TL] + jo0[s * kTab];
-              if (deep) pk += jo1[s * kTab] + jo2[s * kTab];
-              const double *tt = tcf + (pk & 0xffffu);
-              const double *ll = lkT + (pk >> 16);
-              v[k][0] = tt[0] * ll[0];
-              v[k][1] = tt[9] * ll[1];
-              v[k][2] = tt[18] * ll[2];
+                for (int i = 0; i < kStepSlots; ++i) rec.w[i] += r1.w[i] + r2.w[i];
+              }
+#pragma unroll
+              for (int s = 0; s < kMaxList - 1; ++s)
+                if (s < P.nB) {
+                  const uint32_t pk = rowB[s] + rec.w[(L + s) % kStepSlots];
+                  pj = pj * (lds_f64(tcf, pk & 0xffffu) * lds_f64(lkT, pk >> 16));
+                }
+              if (!LOWINV) load_low<L>(v, R, Sall, rowL, &rec, tcf, lkT);
             }
-            const double tot = low_tree<0, L>(pj, v, lb);
+            low_tree<0, L>(pj, v, R, lb);
+            const double tot = pj * Sall;
             sub1 += tot;
-            const uint32_t dg = jdig[j0];
-            for (int d = 0; d < P.jd0; ++d) {
-              const int col = 3 * L + 3 * d + ((dg >> (2 * d)) & 3);
-              s_red[col * BT + tid] += tot;
+            if (stepped) {
+              const uint32_t dg = jdig[j0];
+              for (int d = 0; d < P.jd0; ++d) {
+                const int col = 3 * L + 3 * d + ((dg >> (2 * d)) & 3);
+                s_red[col * BT + tid] += tot;
+              }
             }
           }
           sub2 += sub1;
           if (deep) {
-            const uint32_t dg = jdig[kTab + j1];
+            const uint32_t dg = jdig[kIterTab + j1];
             for (int d = 0; d < P.jd1; ++d) {
               const int col = 3 * L + 3 * (kIterDigitsPerLevel + d) + ((dg >> (2 * d)) & 3);
               s_red[col * BT + tid] += sub1;
@@ -229,7 +285,7 @@ __global__ __launch_bounds__(1024) void bn_enum_kernel(const KParams P, const ui
         }
         total += sub2;
         if (deep) {
-          const uint32_t dg = jdig[2 * kTab + j2];
+          const uint32_t dg = jdig[2 * kIterTab + j2];
           for (int d = 0; d < P.jd2; ++d) {
             const int col = 3 * L + 3 * (2 * kIterDigitsPerLevel + d) + ((dg >> (2 * d)) & 3);
             s_red[col * BT + tid] += sub2;
@@ -305,13 +361,13 @@ __global__ __launch_bounds__(1024) void bn_enum_kernel(const KParams P, const ui
 using KernelFn = void (*)(const KParams, const uint32_t *, const double *, const long, const double *,
                           const uint8_t *, double *, double *, uint8_t *);
 
-KernelFn kernel_for(int L) {
+KernelFn kernel_for(int L, bool lowinv) {
   switch (L) {
-    case 1: return bn_enum_kernel<1>;
-    case 2: return bn_enum_kernel<2>;
-    case 3: return bn_enum_kernel<3>;
-    case 4: return bn_enum_kernel<4>;
-    case 5: return bn_enum_kernel<5>;
+    case 1: return lowinv ? bn_enum_kernel<1, true> : bn_enum_kernel<1, false>;
+    case 2: return lowinv ? bn_enum_kernel<2, true> : bn_enum_kernel<2, false>;
+    case 3: return lowinv ? bn_enum_kernel<3, true> : bn_enum_kernel<3, false>;
+    case 4: return lowinv ? bn_enum_kernel<4, true> : bn_enum_kernel<4, false>;
+    case 5: return lowinv ? bn_enum_kernel<5, true> : bn_enum_kernel<5, false>;
   }
   return nullptr;
 }
@@ -327,8 +383,9 @@ KParams make_kparams(const Plan &p, double lc) {
   k.jd0 = p.jd[0]; k.jd1 = p.jd[1]; k.jd2 = p.jd[2];
   k.jlevels = p.jlevels;
   k.cols = p.cols; k.parts = p.parts;
-  k.off_joff = p.n_slots * p.team_lanes;
-  k.off_jdig = k.off_joff + kIterLevels * p.n_slots * kIterTab;
+  k.row_stride = p.row_stride;
+  k.off_joff = (p.row_stride * p.team_lanes + 3) & ~3;  // 16-byte aligned: step records are read as uint4
+  k.off_jdig = k.off_joff + kIterLevels * kIterTab * kStepSlots;
   k.off_minfo = k.off_jdig + kIterLevels * kIterTab;
   const LdsLayout l = lds_layout(p);
   size_t o = 0;
@@ -362,7 +419,7 @@ void build_factor_tables(const famseq_model &m, double *tc) {
 }
 
 int bn_enum_blocks_per_cu(const Plan &p, hipError_t *err) {
-  KernelFn fn = kernel_for(p.L);
+  KernelFn fn = kernel_for(p.L, p.low_invariant != 0);
   if (!fn) {
     if (err) *err = hipErrorInvalidValue;
     return -1;
@@ -380,7 +437,7 @@ int bn_enum_blocks_per_cu(const Plan &p, hipError_t *err) {
 hipError_t launch_bn_enum(const Plan &p, const KParams &kp, int grid_blocks, const uint32_t *d_img,
                           const double *d_tc, int64_t n_sites, const double *d_lk, const uint8_t *d_flags,
                           double *d_post, double *d_single, uint8_t *d_status, hipStream_t stream) {
-  KernelFn fn = kernel_for(p.L);
+  KernelFn fn = kernel_for(p.L, p.low_invariant != 0);
   if (!fn) return hipErrorInvalidValue;
   if (n_sites <= 0) return hipSuccess;
   // host-side shape checks: the kernel indexes LDS with these and nothing else

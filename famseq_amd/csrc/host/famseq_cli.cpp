@@ -1,0 +1,774 @@
+// famseq_cli.cpp — FamSeq-compatible command line over libfamseq_hip's C ABI.
+//
+// Keeps the reference's CLI and file surface for the `-method 1` path:
+//   FamSeq vcf -vcfFile f -pedFile p -output o [-v] [-a] [-d] [-o] [-l loc] [-method 1]
+//              [-mRate r] [-genoProbN a b c] [-genoProbK a b c] [-genoProbXN a c]
+//              [-genoProbXK a c] [-LRC x]
+//   FamSeq LK  -lkFile f -pedFile p -output o [-lkType n|log10|ln|PS] [...]
+// Reference behaviour being reproduced (all cites /root/reference/src):
+//   flag parsing + defaults + messages   checkInput.cpp:149-578, 671-1067; FamSeq.cpp:28-156
+//   readPed / setFam                     file.cpp:24-62, 1888-1968
+//   VCF driver                           file.cpp:108-1004  (header rewrite :143-196, column
+//                                        mapping :200-232, location filter :235-360, site rules
+//                                        :362-473, Known/chrType :476-486, missing samples
+//                                        :488-518, PL/GL -> likelihood :584-592/:821-828,
+//                                        failure output :607-620, Phred text :684-765/:922-1001)
+//   LK driver                            file.cpp:1640-1886
+// Differences by design: ONE pass over the input (the reference reads the file twice), sites are
+// queued and evaluated in batches on the GPU (famseq_bn_batch) with the output order preserved,
+// and only -method 1 exists here (methods 2/3 are other algorithms, out of scope).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "famseq_hip.h"
+
+namespace {
+
+using std::string;
+using std::vector;
+
+// ---- small text helpers ------------------------------------------------------------------
+
+// normal.cpp:15-53 with trim=false: empty tokens are kept, including a trailing one.
+vector<string> split_keep(const string &s, char sep) {
+  vector<string> out;
+  if (s.empty()) return out;
+  size_t head = 0, tail;
+  while ((tail = s.find(sep, head)) != string::npos) {
+    out.emplace_back(s, head, tail - head);
+    head = tail + 1;
+  }
+  out.emplace_back(s, head);
+  return out;
+}
+
+// default ostream formatting of a double (precision 6, general)
+void put_double(string &out, double v) {
+  char buf[40];
+  std::snprintf(buf, sizeof buf, "%g", v);
+  out += buf;
+}
+
+// fabs(-10*log10(p)), +inf -> 99999  (file.cpp:696-703)
+void put_phred(string &out, double p) {
+  const double q = -10 * std::log10(p);
+  if (q == std::numeric_limits<double>::infinity()) out += "99999";
+  else put_double(out, std::fabs(q));
+}
+
+// pow(10, -|x|/10) for a PL/GL field (file.cpp:588-590).  Integer fields (the usual PL) go
+// through a table filled with the same libm pow call, so the value is identical.
+struct PlTable {
+  vector<double> lut;
+  PlTable() : lut(4096) {
+    for (size_t k = 0; k < lut.size(); ++k) lut[k] = std::pow(10.0, -std::fabs(double(k)) / 10.0);
+  }
+  double operator()(const char *b, const char *e) const {
+    unsigned v = 0;
+    const char *p = b;
+    while (p < e && *p >= '0' && *p <= '9' && v < 100000) v = v * 10 + unsigned(*p++ - '0');
+    if (p == e && p > b && v < lut.size()) return lut[v];
+    const double x = std::atof(string(b, e).c_str());
+    return std::pow(10.0, -std::fabs(x) / 10.0);
+  }
+};
+
+// ---- options -----------------------------------------------------------------------------
+
+struct Options {
+  bool lk_mode = false;
+  vector<string> vcf_files;
+  string lk_file, ped_file, out_file, loc_file;
+  bool var_only = false, all_line = false, diff_only = false, pos_order = false;
+  int method = 1, lk_type = 1;
+  double mrate = 1e-7, lrc = 1;
+  vector<double> gN, gK, gXN, gXK;
+  int num_burn = -999, num_rep = -999;
+};
+
+// returns 0 good, 1 warnings, -1 stop (checkInput.h:345-349)
+int parse_options(int argc, char **argv, Options &o) {
+  int rv = 0;
+  auto missing = [&](int i) { return i == argc || argv[i][0] == '-'; };
+  for (int i = 2; i < argc; i++) {
+    if (argv[i][0] != '-') {
+      std::cout << "Cannot recognize parameter: \"" << argv[i] << "\" in the command." << std::endl;
+      rv = 1;
+      continue;
+    }
+    const string opt(argv[i] + 1);
+    auto need_file = [&](string &dst, const char *what) {
+      i++;
+      if (missing(i)) {
+        std::cout << "The " << what << " hasn't been set. Please check input." << std::endl;
+        return false;
+      }
+      dst = argv[i];
+      return true;
+    };
+    auto probs = [&](vector<double> &dst, int n, const char *msg) {
+      vector<double> tmp(3, 0);
+      for (int j = 0; j < n; j++) {
+        i++;
+        if (missing(i)) {
+          std::cout << msg << std::endl;
+          i--;
+          rv = 1;
+          return;
+        }
+        tmp[n == 3 ? j : 2 * j] = std::atof(argv[i]);  // X priors: {a, 0, c} (checkInput.cpp:340-372)
+      }
+      dst = tmp;
+    };
+    if (!o.lk_mode && opt == "vcfFile") {
+      bool first = true;
+      while (true) {
+        i++;
+        if (first && missing(i)) {
+          std::cout << "The vcf file hasn't been set. Please check input." << std::endl;
+          return -1;
+        }
+        first = false;
+        if (missing(i)) {
+          i--;
+          break;
+        }
+        o.vcf_files.push_back(argv[i]);
+      }
+    } else if (o.lk_mode && opt == "lkFile") {
+      if (!need_file(o.lk_file, "likelihood file")) return -1;
+    } else if (opt == "pedFile") {
+      if (!need_file(o.ped_file, "ped file")) return -1;
+    } else if (!o.lk_mode && opt == "l") {
+      if (!need_file(o.loc_file, "location file")) return -1;
+    } else if (opt == "output") {
+      if (!need_file(o.out_file, "output file")) return -1;
+    } else if (!o.lk_mode && opt == "v") {
+      o.var_only = true;
+    } else if (!o.lk_mode && opt == "a") {
+      o.all_line = true;
+    } else if (!o.lk_mode && opt == "d") {
+      o.diff_only = true;
+    } else if (!o.lk_mode && opt == "o") {
+      o.pos_order = true;
+    } else if (opt == "method") {
+      i++;
+      if (missing(i)) {
+        std::cout << "Method hasn't been set. The default method (BN) will be used." << std::endl;
+        i--;
+        rv = 1;
+      } else {
+        o.method = std::atoi(argv[i]);
+      }
+    } else if (opt == "mRate") {
+      i++;
+      if (missing(i)) {
+        std::cout << "Mutation rate hasn't been set. The default (1e-7) will be used." << std::endl;
+        i--;
+        rv = 1;
+      } else {
+        o.mrate = std::atof(argv[i]);
+      }
+    } else if (o.lk_mode && opt == "lkType") {
+      i++;
+      if (missing(i)) {
+        std::cout << "Likelihood type hasn't been set. The default normal (n) will be used." << std::endl;
+        i--;
+        rv = 1;
+      } else {
+        const string t(argv[i]);
+        if (t == "n") o.lk_type = 1;
+        else if (t == "log10") o.lk_type = 2;
+        else if (t == "ln") o.lk_type = 3;
+        else if (t == "PS") o.lk_type = 4;
+        else {
+          std::cout << "Cannot recognize the likelihood type: " << t << ". The default normal (n) will be used." << std::endl;
+          o.lk_type = 1;
+          rv = 1;
+        }
+      }
+    } else if (opt == "genoProbN") {
+      probs(o.gN, 3, "genoProbN hasn't been set. The default (0.9985,0.001,0.0005) will be used.");
+    } else if (opt == "genoProbK") {
+      probs(o.gK, 3, "genoProbK hasn't been set. The default (0.45,0.1,0.45) will be used.");
+    } else if (opt == "genoProbXN") {
+      probs(o.gXN, 2, "genoProbN hasn't been set. The default (0.999,0.001) will be used.");
+    } else if (opt == "genoProbXK") {
+      probs(o.gXK, 2, "genoProbN hasn't been set. The default (0.5,0.5) will be used.");
+    } else if (opt == "numBurnIn" || opt == "numRep") {
+      i++;
+      if (missing(i)) {
+        std::cout << "Number of " << (opt == "numRep" ? "MCMC repeat" : "burn in")
+                  << " times hasn't been set. The default will be used." << std::endl;
+        i--;
+        rv = 1;
+      } else {
+        (opt == "numRep" ? o.num_rep : o.num_burn) = std::atoi(argv[i]);
+      }
+    } else if (opt == "LRC") {
+      i++;
+      if (missing(i)) {
+        std::cerr << "Likelihood ratio criteria is not set. The default will be used." << std::endl;
+        i--;
+        rv = 1;
+      } else {
+        o.lrc = std::atof(argv[i]);
+      }
+    } else {
+      std::cout << "Cannot recognize option: \"" << opt << "\" in the command." << std::endl;
+      rv = 1;
+    }
+  }
+  if (!o.lk_mode && o.vcf_files.empty()) {
+    std::cout << "The name of vcf file must be set. Please input the vcf file name." << std::endl;
+    return -1;
+  }
+  if (o.lk_mode && o.lk_file.empty()) {
+    std::cout << "The name of likelihood file must be set. Please input the likelihood file name." << std::endl;
+    return -1;
+  }
+  if (o.ped_file.empty()) {
+    std::cout << "The name of ped file must be set. Please input the ped file name." << std::endl;
+    return -1;
+  }
+  if (o.out_file.empty()) {
+    std::cout << "The name of output file must be set. Please input the output file name." << std::endl;
+    return -1;
+  }
+  if (o.method < 1 || o.method > 3) {
+    std::cout << "Method could only be 1 or 3. The default method (BN) will be used." << std::endl;
+    o.method = 1;
+    rv = 1;
+  }
+  if (o.mrate < 0 || o.mrate > 0.5) {
+    std::cout << "Mutation rate is set out of range. The default (1e-7) will be used." << std::endl;
+    o.mrate = 1e-7;
+    rv = 1;
+  }
+  if (o.var_only && o.all_line) {
+    std::cout << "varOnly is setted, allLine is blocked." << std::endl;
+    o.all_line = false;
+    rv = 1;
+  }
+  if (o.lrc < 0) {
+    std::cerr << "Likelihood ration criteria is not set correctly. The default will be used." << std::endl;
+    o.lrc = 1;
+    rv = 1;
+  }
+  if (o.diff_only) {  // file.cpp:124-128
+    o.all_line = false;
+    o.var_only = true;
+  }
+  return rv;
+}
+
+// ---- pedigree ------------------------------------------------------------------------------
+
+struct Ped {
+  vector<int32_t> id, mid, fid, gender;
+  vector<string> name;
+  int n() const { return (int)id.size(); }
+};
+
+bool read_ped(const string &path, Ped &p) {  // file.cpp:24-62
+  std::ifstream fin(path.c_str());
+  if (!fin.is_open()) {
+    std::cout << "Cannot open " << path << std::endl;
+    return false;
+  }
+  string line;
+  std::getline(fin, line);
+  while (std::getline(fin, line)) {
+    if (line.size() < 2) break;
+    std::istringstream in(line);
+    int a = 0, b = 0, c = 0, d = 0;
+    string nm;
+    in >> a >> b >> c >> d >> nm;
+    p.id.push_back(a);
+    p.mid.push_back(b);
+    p.fid.push_back(c);
+    p.gender.push_back(d);
+    p.name.push_back(nm);
+  }
+  return true;
+}
+
+// ---- batched caller: queue of output records, flushed through the GPU in order -------------
+
+struct Record {
+  string text;              // literal line, or the prefix of a computed line (cols 1-8 + FORMAT + tags)
+  long site = -1;           // index into the pending batch, -1 for literal records
+  vector<string> fields;    // per sequenced sample: original text to print before ':'
+  vector<string> fail_fields;  // per sequenced sample: text for the :NA:NA:NA line (vsLine[9+i] / vsLine[i])
+  string raw;               // the input line, for the warning on failure
+};
+
+class BatchCaller {
+ public:
+  BatchCaller(famseq_ctx *ctx, int n_members, const vector<int> &seq_members, std::ostream &out, size_t cap)
+      : ctx_(ctx), n_(n_members), seq_(seq_members), out_(out), cap_(cap) {}
+
+  void literal(string line) {
+    Record r;
+    r.text = std::move(line);
+    q_.push_back(std::move(r));
+  }
+  // lk: N x 3 in PED order
+  bool site(Record &&r, const vector<double> &lk, uint8_t flags) {
+    r.site = (long)flags_.size();
+    lk_.insert(lk_.end(), lk.begin(), lk.end());
+    flags_.push_back(flags);
+    q_.push_back(std::move(r));
+    return flags_.size() < cap_ || flush();
+  }
+  bool flush() {
+    const int64_t s = (int64_t)flags_.size();
+    post_.resize(lk_.size());
+    single_.resize(lk_.size());
+    status_.resize(flags_.size());
+    if (s > 0) {
+      const int rc = famseq_bn_batch(ctx_, s, lk_.data(), flags_.data(), post_.data(), single_.data(), status_.data());
+      if (rc != 0) {
+        std::cerr << "famseq_bn_batch failed (" << rc << "): " << famseq_last_error(ctx_) << std::endl;
+        return false;
+      }
+    }
+    string line;
+    vector<int8_t> gt(seq_.size());
+    vector<double> rows(3 * seq_.size());
+    for (Record &r : q_) {
+      line.assign(r.text);
+      if (r.site >= 0) {
+        const size_t base = size_t(r.site) * 3 * n_;
+        if (status_[r.site] & 3) {  // file.cpp:607-620
+          std::cout << "Warning: this variant hasn't been calculated: " << std::endl << r.raw << std::endl;
+          for (const string &f : r.fail_fields) line += f + ":NA:NA:NA\t";
+        } else {
+          for (size_t k = 0; k < seq_.size(); ++k)
+            for (int g = 0; g < 3; ++g) rows[3 * k + g] = post_[base + 3 * seq_[k] + g];
+          famseq_call_genotypes(rows.data(), (int64_t)seq_.size(), gt.data());
+          for (size_t k = 0; k < seq_.size(); ++k) {
+            const double *sp = &single_[base + 3 * seq_[k]], *pp = &rows[3 * k];
+            line += r.fields[k];
+            put_phred(line, sp[0]); line += ',';
+            put_phred(line, sp[1]); line += ',';
+            put_phred(line, sp[2]); line += ':';
+            put_phred(line, pp[0]); line += ',';
+            put_phred(line, pp[1]); line += ',';
+            put_phred(line, pp[2]); line += ':';
+            line += gt[k] == 0 ? "0/0\t" : (gt[k] == 1 ? "0/1\t" : "1/1\t");
+          }
+        }
+      }
+      out_ << line << '\n';
+    }
+    q_.clear();
+    lk_.clear();
+    flags_.clear();
+    return true;
+  }
+
+ private:
+  famseq_ctx *ctx_;
+  int n_;
+  vector<int> seq_;  // PED index of each sequenced output column, in input column order
+  std::ostream &out_;
+  size_t cap_;
+  vector<Record> q_;
+  vector<double> lk_, post_, single_;
+  vector<uint8_t> flags_, status_;
+};
+
+size_t batch_capacity() {
+  const char *e = std::getenv("FAMSEQ_BATCH");
+  const long v = e ? std::atol(e) : 0;
+  return v > 0 ? size_t(v) : size_t(1) << 16;
+}
+
+// ---- model + ctx ---------------------------------------------------------------------------
+
+famseq_ctx *make_ctx(const Options &o, const Ped &ped, const vector<uint8_t> &sequenced, famseq_model &m) {
+  const int rc = famseq_model_init(&m, ped.n(), ped.id.data(), ped.mid.data(), ped.fid.data(), ped.gender.data(),
+                                   sequenced.data(), o.mrate, o.lrc);
+  if (rc == FAMSEQ_E_PED_HALF) std::cout << "This is not a fulfill family. Please check the ped file." << std::endl;
+  if (rc == FAMSEQ_E_PED_SEX) std::cerr << "A mother is not a female or a father is not a male in the ped file." << std::endl;
+  if (rc != 0) {
+    std::cout << "Cannot initiate family. Please check ped file." << std::endl;
+    return nullptr;
+  }
+  auto put = [](double *dst, const vector<double> &src) {
+    if (src.size() == 3) std::copy(src.begin(), src.end(), dst);
+  };
+  put(m.genoProbN, o.gN);
+  put(m.genoProbK, o.gK);
+  put(m.genoProbXN, o.gXN);
+  put(m.genoProbXK, o.gXK);
+  const char *dev = std::getenv("FAMSEQ_DEVICE");
+  char err[512] = {0};
+  famseq_ctx *ctx = famseq_create(&m, dev ? std::atoi(dev) : 0, err, sizeof err);
+  if (!ctx) std::cerr << "Cannot create the GPU context: " << err << std::endl;
+  return ctx;
+}
+
+void put_triple(std::ostream &o, const double *p) { o << p[0] << ":" << p[1] << ":" << p[2]; }
+
+// ---- VCF driver ----------------------------------------------------------------------------
+
+int chrom_number(const string &c) {  // file.cpp:321-343
+  if (c == "X" || c == "chrX") return 23;
+  if (c == "Y" || c == "chrY") return 24;
+  if (c == "MT") return 25;
+  return std::atoi(c.compare(0, 3, "chr") == 0 ? c.c_str() + 3 : c.c_str());
+}
+
+bool run_vcf(const Options &o, const Ped &ped) {
+  std::ifstream fin(o.vcf_files[0].c_str());
+  if (!fin.is_open()) {
+    std::cout << "Cannot open " << o.vcf_files[0] << std::endl;
+    return false;
+  }
+  famseq_model m;
+  // defaults needed for the header before the ctx exists
+  {
+    vector<uint8_t> all(ped.n(), 1);
+    if (famseq_model_init(&m, ped.n(), ped.id.data(), ped.mid.data(), ped.fid.data(), ped.gender.data(), all.data(),
+                          o.mrate, o.lrc) != 0) {
+      std::cout << "Cannot initiate family. Please check ped file." << std::endl << "Cannot set family." << std::endl;
+      return false;
+    }
+    if (o.gN.size() == 3) std::copy(o.gN.begin(), o.gN.end(), m.genoProbN);
+    if (o.gK.size() == 3) std::copy(o.gK.begin(), o.gK.end(), m.genoProbK);
+    if (o.gXN.size() == 3) std::copy(o.gXN.begin(), o.gXN.end(), m.genoProbXN);
+    if (o.gXK.size() == 3) std::copy(o.gXK.begin(), o.gXK.end(), m.genoProbXK);
+  }
+  std::ofstream fout(o.out_file.c_str());
+
+  // ---- header (file.cpp:143-196): lines are echoed with a one-line lag
+  auto format_tags = [&](bool fallback) {
+    fout << "##FORMAT=<ID=GPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
+         << (fallback ? "calbulated by Single Method" : "calculated by individual-based Method") << "\">" << std::endl;
+    fout << "##FORMAT=<ID=FPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
+            "calculated by FamSeqPro\">" << std::endl;
+    fout << "##FORMAT=<ID=FGT,Number=1,Type=String,Description=\"Genotype called by FamSeqPro\">" << std::endl;
+  };
+  auto fs_info = [&] {
+    fout << "##FS mutation rate=" << o.mrate << " " << std::endl;
+    fout << "##FS genotype frequency in pupulation (Rare): "; put_triple(fout, m.genoProbN); fout << std::endl;
+    fout << "##FS genotype frequency in population (Common): "; put_triple(fout, m.genoProbK); fout << std::endl;
+    fout << "##FS genotype frequency for chromosome X of male in population (Rare): "; put_triple(fout, m.genoProbXN); fout << std::endl;
+    fout << "##FS genotype frequency for chromosome X of male in population (Common): "; put_triple(fout, m.genoProbXK); fout << std::endl;
+  };
+  string title, line;
+  bool need_tags = true, need_info = true, have_line = false;
+  while (std::getline(fin, line)) {
+    if (!line.empty() && line[0] == '#') {
+      if (title.size() > 2) {
+        fout << title << std::endl;
+        if (title.compare(2, 6, "FORMAT") == 0 && line.compare(2, 4, "INFO") == 0 && need_tags) {
+          format_tags(false);
+          need_tags = false;
+        }
+        if (line.compare(2, 6, "contig") == 0 && need_info) {
+          fs_info();
+          need_info = false;
+        }
+      }
+      title = line;
+      continue;
+    }
+    have_line = true;
+    break;
+  }
+  if (need_tags) format_tags(true);
+  if (need_info) fs_info();
+
+  // ---- column mapping (file.cpp:200-232)
+  const vector<string> head = split_keep(title, '\t');
+  if (head.size() < 9) {
+    std::cerr << "The vcf file has no #CHROM header line." << std::endl;
+    return false;
+  }
+  const size_t ncol = head.size() - 9;
+  vector<int> v2p(ncol, -1);
+  vector<uint8_t> sequenced(ped.n(), 0);
+  for (size_t i = 0; i < ncol; i++)
+    for (int j = 0; j < ped.n(); j++)
+      if (head[9 + i] == ped.name[j]) {
+        v2p[i] = j;
+        sequenced[j] = 1;
+        break;
+      }
+  vector<int> seq_cols, seq_members;
+  for (size_t i = 0; i < ncol; i++)
+    if (v2p[i] >= 0) {
+      seq_cols.push_back((int)i);
+      seq_members.push_back(v2p[i]);
+    }
+  for (int i = 0; i < 9; i++) fout << head[i] << '\t';
+  for (int c : seq_cols) fout << head[9 + c] << '\t';
+  fout << std::endl;
+
+  // ---- location filter (file.cpp:235-298)
+  vector<vector<int>> loc(25);
+  const bool use_loc = !o.loc_file.empty();
+  if (use_loc) {
+    std::ifstream fl(o.loc_file.c_str());
+    if (!fl.is_open()) {
+      std::cout << "Cannot open " << o.loc_file << std::endl;
+      return false;
+    }
+    string l;
+    while (std::getline(fl, l)) {
+      if (l.size() < 2) break;
+      const vector<string> t = split_keep(l, '\t');
+      if (t.size() < 2) continue;
+      int c = t[0] == "X" ? 23 : t[0] == "Y" ? 24 : t[0] == "MT" ? 25 : std::atoi(t[0].c_str());
+      const int p = std::atoi(t[1].c_str());
+      if (c < 1 || c > 25 || p == 0) continue;
+      loc[c - 1].push_back(p);
+    }
+    for (auto &v : loc) std::sort(v.begin(), v.end());
+  }
+
+  famseq_ctx *ctx = make_ctx(o, ped, sequenced, m);
+  if (!ctx) return false;
+  BatchCaller caller(ctx, ped.n(), seq_members, fout, batch_capacity());
+  const PlTable pl;
+  const size_t n_seq = seq_cols.size();
+  vector<double> lk(size_t(3) * ped.n());
+  bool ok = true;
+
+  auto echo = [&](const vector<string> &t) {  // the "allLine" echo: 9 columns + sequenced samples
+    string s;
+    for (int i = 0; i < 9; i++) s += t[i] + '\t';
+    for (int c : seq_cols) s += t[9 + c] + '\t';
+    caller.literal(std::move(s));
+  };
+
+  for (; have_line && ok; have_line = bool(std::getline(fin, line))) {
+    if (line.size() < 2) break;
+    if (line[0] == '#') continue;
+    const vector<string> t = split_keep(line, '\t');
+    if (t.size() < 9 + ncol) continue;  // malformed line (the reference would read out of bounds)
+    if (use_loc) {
+      const int c = chrom_number(t[0]);
+      const int p = std::atoi(t[1].c_str());
+      if (c < 1 || c > 25 || p == 0) continue;
+      if (!std::binary_search(loc[c - 1].begin(), loc[c - 1].end(), p)) continue;
+    }
+    // site rules, in the reference's order (file.cpp:362-473)
+    if (t[3] == "." || t[3] == "-" || t[3].size() != 1 || t[4].size() != 1) {
+      if (o.all_line) echo(t);
+      continue;
+    }
+    if (o.var_only && (t[4] == "." || t[4] == "-")) continue;
+    if (t[0] == "Y" || t[0] == "chrY" || t[0] == "MT") {
+      if (o.all_line) echo(t);
+      continue;
+    }
+    const bool is_x = t[0] == "X" || t[0] == "chrX" || t[0] == "CHRX";
+    const int cn = std::atoi(t[0].compare(0, 3, "chr") == 0 ? t[0].c_str() + 3 : t[0].c_str());
+    if (!((0 < cn && cn < 23) || is_x)) {
+      if (o.all_line) echo(t);
+      continue;
+    }
+    const uint8_t flags = uint8_t((t[2] != "." ? FAMSEQ_FLAG_KNOWN : 0) | (is_x ? FAMSEQ_FLAG_CHRX : 0));
+    const vector<string> fmt = split_keep(t[8], ':');
+    size_t n_miss = 0;
+    for (int c : seq_cols) n_miss += t[9 + c].size() < 5;
+    if (n_miss == n_seq) {
+      if (o.all_line) echo(t);
+      continue;
+    }
+    int i_pl = -1;
+    for (size_t k = 0; k < fmt.size(); k++)
+      if (fmt[k] == "PL" || fmt[k] == "GL") i_pl = (int)k;
+    if (i_pl < 0) {  // echoed unchanged even without -a (file.cpp:541-555, :770-784)
+      echo(t);
+      continue;
+    }
+    Record r;
+    for (int i = 0; i < 8; i++) r.text += t[i] + '\t';
+    r.text += t[8] + ":GPP:FPP:FGT\t";
+    r.raw = line;
+    std::fill(lk.begin(), lk.end(), 1.0);
+    for (int c : seq_cols) {
+      const string &f = t[9 + c];
+      r.fail_fields.push_back(f);
+      if (f.size() < 5) {  // missing sample: flat likelihood, printed as NA per FORMAT key (file.cpp:927-933)
+        string na;
+        for (size_t k = 0; k < fmt.size(); k++) na += "NA:";
+        r.fields.push_back(na);
+        continue;
+      }
+      r.fields.push_back(f + ":");
+      const vector<string> sub = split_keep(f, ':');
+      if (sub.size() != fmt.size()) continue;  // row stays {1,1,1} (file.cpp:573-578)
+      const string &pls = sub[i_pl];
+      const char *b = pls.c_str(), *end = b + pls.size();
+      for (int g = 0; g < 3; g++) {
+        const char *e = static_cast<const char *>(std::memchr(b, ',', size_t(end - b)));
+        if (!e) e = end;
+        lk[size_t(3) * v2p[c] + g] = pl(b, e);
+        b = e < end ? e + 1 : end;
+      }
+    }
+    ok = caller.site(std::move(r), lk, flags);
+  }
+  ok = ok && caller.flush();
+  famseq_destroy(ctx);
+  return ok;
+}
+
+// ---- LK driver (file.cpp:1640-1886) ----------------------------------------------------------
+
+bool run_lk(const Options &o, const Ped &ped) {
+  std::ifstream fin(o.lk_file.c_str());
+  if (!fin.is_open()) {
+    std::cout << "Cannot open " << o.lk_file << std::endl;
+    return false;
+  }
+  string title, line;
+  std::getline(fin, title);
+  const vector<string> head = split_keep(title, '\t');
+  vector<int> v2p(head.size(), -1);
+  vector<uint8_t> sequenced(ped.n(), 0);
+  for (size_t i = 0; i < head.size(); i++)
+    for (int j = 0; j < ped.n(); j++)
+      if (head[i] == ped.name[j]) {
+        v2p[i] = j;
+        sequenced[j] = 1;
+        break;
+      }
+  famseq_model m;
+  famseq_ctx *ctx = make_ctx(o, ped, sequenced, m);
+  if (!ctx) return false;
+  std::ofstream fout(o.out_file.c_str());
+  fout << "##FORMAT=<ID=GPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
+          "calculated by individual-base Method\">" << std::endl;
+  fout << "##FORMAT=<ID=FPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
+          "calculated by FamSeqPro\">" << std::endl;
+  fout << "##FORMAT=<ID=FGT,Number=1,Type=String,Description=\"Genotype called by FamSeqPro\">" << std::endl;
+  fout << "##FS mutation rate=" << o.mrate << " " << std::endl;
+  fout << "##FS genotype frequency in pupulation: "; put_triple(fout, m.genoProbN); fout << std::endl;
+  vector<int> seq_cols, seq_members;
+  fout << "#FORMAT\t";
+  for (size_t i = 0; i < head.size(); i++)
+    if (v2p[i] >= 0) {
+      seq_cols.push_back((int)i);
+      seq_members.push_back(v2p[i]);
+      fout << head[i] << '\t';
+    }
+  fout << std::endl;
+  BatchCaller caller(ctx, ped.n(), seq_members, fout, batch_capacity());
+  vector<double> lk(size_t(3) * ped.n());
+  bool ok = true;
+  while (ok && std::getline(fin, line)) {
+    if (line.size() < 2) break;
+    const vector<string> t = split_keep(line, '\t');
+    if (!seq_cols.empty() && t.size() <= size_t(seq_cols.back())) continue;  // short row
+    std::fill(lk.begin(), lk.end(), 1.0);
+    Record r;
+    r.text = "LK:GPP:FPP:FGT\t";
+    r.raw = line;
+    for (int c : seq_cols) {
+      r.fields.push_back(t[c] + ":");
+      r.fail_fields.push_back(t[c]);
+      const vector<string> v = split_keep(t[c], ',');
+      for (int g = 0; g < 3 && g < (int)v.size(); g++) {
+        double x = std::atof(v[g].c_str());
+        if (o.lk_type == 2) x = std::pow(10.0, x);
+        else if (o.lk_type == 3) x = std::exp(x);
+        else if (o.lk_type == 4) x = std::pow(10.0, -x / 10.0);
+        lk[size_t(3) * v2p[c] + g] = x;
+      }
+    }
+    ok = caller.site(std::move(r), lk, 0);  // calPostProbBN() defaults: Known=false, chrType=0 (file.cpp:1751)
+  }
+  ok = ok && caller.flush();
+  famseq_destroy(ctx);
+  return ok;
+}
+
+void usage_top() {
+  std::cout << std::endl
+            << "Program: FamSeq (Sequence calling using pedigree information), MI355X build of the -method 1 path"
+            << std::endl << "Usage:\tFamSeq <input type> [options]" << std::endl << std::endl
+            << "Input type: \tvcf\t\tinput vcf file" << std::endl << "\t\tLK\t\tinput likelihood file" << std::endl
+            << std::endl << "Type FamSeq -h for help." << std::endl << std::endl;
+}
+
+void help() {
+  std::cout << "Usage:\tFamSeq <input type> [options]" << std::endl << std::endl
+            << "FamSeq vcf [options] for vcf input, FamSeq LK [options] for likelihood-only input." << std::endl
+            << std::endl << "Options:" << std::endl << std::endl
+            << "-vcfFile\tThe name of input vcf file." << std::endl
+            << "-lkFile\t\tThe name of input likelihood only format file." << std::endl
+            << "-lkType\t\tn:normal(default); log10: log10 scaled; ln: ln scaled; PS: phred scaled." << std::endl
+            << "-pedFile\tThe name of the file storing the pedigree information." << std::endl
+            << "-output\t\tThe name of output file" << std::endl
+            << "-method\t\t1(default): Bayesian network (the only method of this build)." << std::endl
+            << "-mRate\t\tMutation rate. The default value is 1e-7" << std::endl
+            << "-v\t\tOnly record the position at which the genotype is not RR in the output file." << std::endl
+            << "-a\t\tRecord all the position in the output file." << std::endl
+            << "-l\t\tLocation file (chromosome<TAB>position): only these positions are processed." << std::endl
+            << "-genoProbN\tPr(G) for autosome, variant not in dbSNP. Default 0.9985 0.001 0.0005." << std::endl
+            << "-genoProbK\tPr(G) for autosome, variant in dbSNP. Default 0.45 0.1 0.45." << std::endl
+            << "-genoProbXN\tPr(G) for chromosome X of males, not in dbSNP. Default 0.999 0.001." << std::endl
+            << "-genoProbXK\tPr(G) for chromosome X of males, in dbSNP. Default 0.5 0.5." << std::endl
+            << "-LRC\t\tLikelihood ratio criterion for the single-sample shortcut. Default 1." << std::endl
+            << "Environment: FAMSEQ_DEVICE (GPU index, default 0), FAMSEQ_BATCH (sites per GPU batch)." << std::endl;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc == 1) {
+    usage_top();
+    return -1;
+  }
+  const string mode(argv[1]);
+  if (mode == "-h") {
+    help();
+    return 0;
+  }
+  if (mode != "vcf" && mode != "LK") {
+    std::cout << "Cannot recognize the input type: \"" << argv[1] << "\"." << std::endl
+              << "The input type can only be vcf or LK" << std::endl << std::endl
+              << "Type FamSeq -h for help." << std::endl;
+    return -1;
+  }
+  if (argc == 2) {
+    std::cout << std::endl << "Usage:\tFamSeq " << mode << " [options]" << std::endl << std::endl
+              << "Type FamSeq -h for help." << std::endl;
+    return -1;
+  }
+  Options o;
+  o.lk_mode = mode == "LK";
+  const int rc = parse_options(argc, argv, o);
+  if (rc < 0) return -1;
+  if (rc > 0)
+    std::cout << "There are some improper parameters in the command line. Some parameters are set to default."
+              << std::endl;
+  if (o.method != 1) {
+    std::cout << "This build implements -method 1 (Bayesian network) only; methods 2 and 3 are not part of it."
+              << std::endl;
+    return -1;
+  }
+  Ped ped;
+  if (!read_ped(o.ped_file, ped)) {
+    std::cout << "Cannot read Ped file: " << o.ped_file << "." << std::endl << "Cannot set family." << std::endl;
+    return -1;
+  }
+  const bool ok = o.lk_mode ? run_lk(o, ped) : run_vcf(o, ped);
+  return ok ? 0 : -1;
+}

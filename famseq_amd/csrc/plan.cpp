@@ -30,7 +30,7 @@ LdsLayout lds_layout(const Plan &p) {
   LdsLayout l{};
   const size_t bins = size_t(p.teams_per_block) * 3 * p.N;
   l.tc = align16(4 * 4 * 27 * sizeof(double));
-  l.laneoff = align16(size_t(p.n_slots) * p.team_lanes * sizeof(uint32_t));
+  l.laneoff = align16(size_t(p.row_stride) * p.team_lanes * sizeof(uint32_t));
   l.lk = align16(bins * sizeof(double));
   l.flags = align16(size_t(p.teams_per_block) * 4 * sizeof(int32_t) + FAMSEQ_MAX_MEMBERS * sizeof(int32_t));
   l.red = align16(size_t(p.cols) * p.block_threads * sizeof(double));
@@ -78,28 +78,51 @@ Plan build_plan(const famseq_model &m, const PlanOptions &opt) {
   for (int i = 0; i < N; ++i)
     if (!is_low[i]) high.push_back(i);
   const int H = high.size();
-  int A = std::min(H, 5);
+  // Measured on MI355X (ped10): per-site fixed costs (cross-lane reduction, barriers) dominate with
+  // wide teams, so by default a site gets at most 81 lanes and iterates over the rest.
+  int A = std::min(H, 4);
   if (opt.fixed_digits >= 0) A = std::min(H, std::min(opt.fixed_digits, kMaxFixed));
   const int J = H - A;
   if (J > kIterLevels * kIterDigitsPerLevel) throw std::runtime_error("too many iterated members");
   p.A = A;
   p.J = J;
   p.team_lanes = pow3(A);
-  // members with the fewest children first: an iterated digit forces every factor that
-  // mentions it to be re-evaluated per step, so spend the iter positions on those.
-  std::stable_sort(high.begin(), high.end(), [&](int a, int b) { return nchild[a] < nchild[b]; });
-  p.iter_member.assign(high.begin(), high.begin() + J);
-  p.fixed_member.assign(high.begin() + J, high.end());
-  std::sort(p.iter_member.begin(), p.iter_member.end());
-  std::sort(p.fixed_member.begin(), p.fixed_member.end());
+  // Which high members are iterated?  An iterated digit forces every factor that mentions it to
+  // be re-evaluated at every step, and if it is the parent of a low member the low factors can
+  // no longer be hoisted out of the step loop.  Greedy: add, J times, the member whose addition
+  // keeps (B-list length, low dependence) cheapest.
+  {
+    std::vector<char> in_iter(N, 0);
+    auto cost = [&]() {
+      int nb = 0, lowdep = 0;
+      for (int i = 0; i < N; ++i) {
+        const bool dep = in_iter[i] || (m.mother[i] >= 0 && (in_iter[m.mother[i]] || in_iter[m.father[i]]));
+        if (!dep) continue;
+        if (is_low[i]) lowdep = 1; else nb++;
+      }
+      return 3 * nb + (lowdep ? 4 * L : 0);
+    };
+    for (int q = 0; q < J; ++q) {
+      int best = -1, best_cost = 1 << 30;
+      for (int i : high) {
+        if (in_iter[i]) continue;
+        in_iter[i] = 1;
+        const int c = cost() * 64 + nchild[i];  // tie-break: fewer children
+        in_iter[i] = 0;
+        if (c < best_cost) best_cost = c, best = i;
+      }
+      in_iter[best] = 1;
+    }
+    for (int i : high) (in_iter[i] ? p.iter_member : p.fixed_member).push_back(i);
+  }
   std::vector<int> fixed_pos(N, -1), iter_pos(N, -1);
   for (int q = 0; q < A; ++q) fixed_pos[p.fixed_member[q]] = q;
   for (int q = 0; q < J; ++q) iter_pos[p.iter_member[q]] = q;
 
   p.block_threads = p.team_lanes > 256 ? 768 : 256;
   if (opt.block_threads > 0) {
-    if (opt.block_threads % 64 || opt.block_threads > 1024 || opt.block_threads < p.team_lanes)
-      throw std::runtime_error("block_threads must be a multiple of 64, <= 1024 and >= 3^A");
+    if (opt.block_threads % 64 || opt.block_threads > 768 || opt.block_threads < p.team_lanes)
+      throw std::runtime_error("block_threads must be a multiple of 64, <= 768 and >= 3^A");
     p.block_threads = opt.block_threads;
   }
   p.teams_per_block = p.block_threads / p.team_lanes;
@@ -124,14 +147,17 @@ Plan build_plan(const famseq_model &m, const PlanOptions &opt) {
   p.nA = listA.size();
   p.nB = listB.size();
   p.slot_member = listA;
-  p.slot_member.insert(p.slot_member.end(), listB.begin(), listB.end());
   p.slot_member.insert(p.slot_member.end(), p.low_member.begin(), p.low_member.end());
+  p.slot_member.insert(p.slot_member.end(), listB.begin(), listB.end());
   p.n_slots = p.slot_member.size();
+  p.row_stride = p.n_slots | 1;
+  p.low_invariant = 1;
+  for (int i : p.low_member)
+    if (touches_iter(i)) p.low_invariant = 0;
 
-  // ---- packed offsets
-  // term(i, who, coef): contribution of member `who`'s digit to member i's table index
-  p.laneoff.assign(size_t(p.n_slots) * p.team_lanes, 0);
-  p.joff.assign(size_t(kIterLevels) * p.n_slots * kIterTab, 0);
+  // ---- packed byte offsets: lane part per (lane, entry), step part per (level, step, step slot)
+  p.laneoff.assign(size_t(p.team_lanes) * p.row_stride, 0);
+  p.joff.assign(size_t(kIterLevels) * kIterTab * kStepSlots, 0);
   p.jdigits.assign(size_t(kIterLevels) * kIterTab, 0);
   for (int s = 0; s < p.n_slots; ++s) {
     const int i = p.slot_member[s];
@@ -151,8 +177,13 @@ Plan build_plan(const famseq_model &m, const PlanOptions &opt) {
         tidx += d.tcoef * dig;
         lkidx += d.lkcoef * dig;
       }
-      p.laneoff[size_t(s) * p.team_lanes + t] = (lkidx << 16) | tidx;
+      p.laneoff[size_t(t) * p.row_stride + s] = (8 * lkidx) << 16 | (8 * tidx);
     }
+    // step record position: low member k -> k, B-list entry b -> L + b; A-list entries have none
+    int rec = -1;
+    if (s >= p.nA && s < p.nA + L) rec = s - p.nA;
+    if (s >= p.nA + L) rec = L + (s - p.nA - L);
+    if (rec < 0) continue;
     for (int l = 0; l < kIterLevels; ++l)
       for (int jl = 0; jl < p.jn[l]; ++jl) {
         uint32_t tidx = 0, lkidx = 0;
@@ -163,7 +194,7 @@ Plan build_plan(const famseq_model &m, const PlanOptions &opt) {
           tidx += d.tcoef * dig;
           lkidx += d.lkcoef * dig;
         }
-        p.joff[(size_t(l) * p.n_slots + s) * kIterTab + jl] = (lkidx << 16) | tidx;
+        p.joff[(size_t(l) * kIterTab + jl) * kStepSlots + rec] = (8 * lkidx) << 16 | (8 * tidx);
       }
   }
   for (int l = 0; l < kIterLevels; ++l)
@@ -190,7 +221,7 @@ std::string Plan::json() const {
   std::ostringstream o;
   o << "{\"N\":" << N << ",\"L\":" << L << ",\"A\":" << A << ",\"J\":" << J << ",\"team_lanes\":" << team_lanes
     << ",\"block_threads\":" << block_threads << ",\"teams_per_block\":" << teams_per_block << ",\"nA\":" << nA
-    << ",\"nB\":" << nB << ",\"n_slots\":" << n_slots << ",\"jlevels\":" << jlevels << ",\"jn\":[" << jn[0] << ","
+    << ",\"nB\":" << nB << ",\"n_slots\":" << n_slots << ",\"row_stride\":" << row_stride << ",\"low_invariant\":" << low_invariant << ",\"step_slots\":" << kStepSlots << ",\"jlevels\":" << jlevels << ",\"jn\":[" << jn[0] << ","
     << jn[1] << "," << jn[2] << "],\"jd\":[" << jd[0] << "," << jd[1] << "," << jd[2] << "],\"cols\":" << cols
     << ",\"parts\":" << parts << ",\"lds_bytes\":" << lds_bytes << ",\"iter_tab\":" << kIterTab << ",";
   json_array(o, "low_member", low_member);
@@ -207,11 +238,12 @@ std::string Plan::json() const {
   return o.str();
 }
 
-// Device image (32-bit words): [laneoff: n_slots*team_lanes][joff: 3*n_slots*243][jdigits: 3*243]
+// Device image (32-bit words): [laneoff: team_lanes*row_stride][joff: 3*243*20][jdigits: 3*243]
 // [member info: N words = kind | sequenced<<2 (filled by the caller) | bin_kind<<3 | bin_index<<5]
 std::vector<uint32_t> Plan::device_image() const {
   std::vector<uint32_t> img;
   img.insert(img.end(), laneoff.begin(), laneoff.end());
+  while (img.size() % 4) img.push_back(0);  // step records are fetched as 16-byte vectors
   img.insert(img.end(), joff.begin(), joff.end());
   for (uint16_t v : jdigits) img.push_back(v);
   for (int i = 0; i < N; ++i) img.push_back(uint32_t(kind[i]) | uint32_t(bin_kind[i]) << 3 | uint32_t(bin_index[i]) << 5);

@@ -33,6 +33,7 @@ constexpr int kMaxFixed = 6;
 constexpr int kIterDigitsPerLevel = 5;  // 3^5 = 243 steps per nested loop
 constexpr int kIterLevels = 3;
 constexpr int kIterTab = 243;
+constexpr int kStepSlots = 20;  // dwords per step record (L + nB <= N <= 20)
 
 // member kinds select the 27-entry factor table (see Tc in bn_kernel.hip)
 enum Kind { kFounderMale = 0, kFounderFemale = 1, kChildMale = 2, kChildFemale = 3 };
@@ -49,7 +50,9 @@ struct Plan {
   int block_threads = 256;
   int teams_per_block = 1;  // sites per workgroup pass
   int nA = 0, nB = 0;       // high members evaluated once per site / once per iter step
-  int n_slots = 0;          // nA + nB + L, in that order
+  int n_slots = 0;          // nA + L + nB, in that order (A list, low members, B list)
+  int row_stride = 1;       // dwords per lane row of `laneoff` (odd: conflict-free ds_read_b32)
+  int low_invariant = 1;    // no low member has an iterated parent: low factors hoisted out of the steps
   int jlevels = 0;          // nested iter loops in use (0..3)
   int jn[kIterLevels] = {1, 1, 1};   // steps per level (3^digits), level 0 innermost
   int jd[kIterLevels] = {0, 0, 0};   // digits per level
@@ -58,10 +61,11 @@ struct Plan {
   std::vector<int> low_member, fixed_member, iter_member;  // digit position -> member
   std::vector<int> slot_member;                            // n_slots
   std::vector<int> kind;                                   // N
-  // packed offsets: low 16 bits = index into the 27-entry table block (kind*27 + 9g + 3gm + gf
-  // minus the parts supplied elsewhere), high 16 bits = index into the site's lk[N][3].
-  std::vector<uint32_t> laneoff;  // [n_slots][team_lanes]
-  std::vector<uint32_t> joff;     // [kIterLevels][n_slots][kIterTab]
+  // packed BYTE offsets: low 16 bits = offset into the 108-double factor-table block of the
+  // site's flag combo (8*(kind*27 + 9g + 3gm + gf), minus the parts supplied elsewhere), high
+  // 16 bits = offset into the site's lk[N][3] (8*(3m + g)).  lane part + step part = address.
+  std::vector<uint32_t> laneoff;  // [team_lanes][row_stride]: entry e of lane t
+  std::vector<uint32_t> joff;     // [kIterLevels][kIterTab][kStepSlots]: k < L low member k, L + s B-list entry s
   std::vector<uint16_t> jdigits;  // [kIterLevels][kIterTab]: 2 bits per digit of the level
   // cross-lane reduction: bin b = 3*member + g
   std::vector<int> bin_kind;      // N: 0 low, 1 iter, 2 fixed

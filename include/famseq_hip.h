@@ -99,7 +99,7 @@ const char *famseq_last_error(famseq_ctx *ctx);
 /* Integer knobs; must be set before the first batch call.  Keys:
  *   "fixed_digits"  A: high members mapped onto lanes (team = 3^A lanes), 0..6
  *   "low_members"   L: childless members enumerated in the unrolled register loop, 1..5
- *   "block_threads" workgroup size (multiple of 64, <= 1024)
+ *   "block_threads" workgroup size (multiple of 64, <= 768)
  *   "grid_blocks"   persistent grid size (0 = auto: CUs x resident blocks)
  *   "chunk_sites"   host-staging chunk of famseq_bn_batch (0 = auto)
  * Returns 0 or FAMSEQ_E_ARG. */

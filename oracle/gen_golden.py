@@ -173,6 +173,70 @@ def main():
     subprocess.check_call([oracle.REF_CLI, "vcf", "-vcfFile", REF + "/TestData/test.vcf", "-pedFile",
                            OUT + "/testdata/fam01.ped", "-output", full, "-method", "1", "-v"], stdout=subprocess.DEVNULL)
 
+    # ---- probe inputs for the CLI surface: chrX, Known, failures,
+    # missing sample, GL, multi-base REF, chrY/MT/odd contigs, location file, custom flags
+    probe_ped = OUT + "/testdata/probe.ped"
+    with open(probe_ped, "w") as f:
+        f.write("ID\tmID\tfID\tgender IndividualName\n1\t0\t0\t1\tpa\n2\t0\t0\t2\tma\n3\t2\t1\t1\tson\n4\t2\t1\t2\tdau")
+    rows = [
+        ("1", 100, ".", "A", "G", "GT:PL", ["0/1:30,0,40", "0/0:0,25,200", "0/1:20,0,35", "0/0:0,12,90"]),
+        ("X", 200, ".", "A", "G", "GT:PL", ["1/1:90,30,0", "0/1:25,0,30", "0/0:0,20,80", "0/1:15,0,40"]),
+        ("chrX", 300, "rs1", "A", "G", "GT:PL", ["0/1:50,0,50", "0/1:25,0,30", "0/0:0,20,80", "0/1:15,0,40"]),
+        ("X", 400, ".", "A", "G", "GT:PL", ["0/1:9999,0,9999", "0/1:25,0,30", "0/0:0,20,80", "0/1:15,0,40"]),
+        ("1", 500, ".", "A", "G", "GT:PL", ["1/1:9999,9999,0", "1/1:9999,9999,0", "0/0:0,9999,9999", "0/0:0,12,90"]),
+        ("1", 600, ".", "A", "G", "GT:PL", ["./.", "0/0:0,30,60", "0/0:0,25,50", "0/0:0,12,90"]),
+        ("1", 700, ".", "A", "G", "GT:GL", ["0/1:-3.0,0,-4.0", "0/0:0,-2.5,-20.0", "0/1:-2.0,0,-3.5", "0/0:0,-1.2,-9.0"]),
+        ("1", 800, "rs8", "AT", "G", "GT:PL", ["0/1:30,0,40", "0/0:0,25,200", "0/1:20,0,35", "0/0:0,12,90"]),
+        ("1", 900, ".", "A", ".", "GT:PL", ["0/0:0,30,400", "0/0:0,25,200", "0/0:0,20,350", "0/0:0,12,90"]),
+        ("Y", 1000, ".", "A", "G", "GT:PL", ["0/1:30,0,40", "0/0:0,25,200", "0/1:20,0,35", "0/0:0,12,90"]),
+        ("MT", 1100, ".", "A", "G", "GT:PL", ["0/1:30,0,40", "0/0:0,25,200", "0/1:20,0,35", "0/0:0,12,90"]),
+        ("GL000207.1", 1200, ".", "A", "G", "GT:PL", ["0/1:30,0,40", "0/0:0,25,200", "0/1:20,0,35", "0/0:0,12,90"]),
+        ("chr7", 1300, "rs13", "C", "T", "GT:DP", ["0/1:30", "0/0:25", "0/1:20", "0/0:12"]),
+        ("22", 1400, ".", "A", "G", "GT:PL", ["./.", "./.", "./.", "./."]),
+        ("2", 1500, ".", "A", "G", "GT:AD:PL", ["0/1:3,4:300,0,400", "0/0:0,250,2000", "0/1:1,1:200,0,350", "0/0:9,0:0,120,900"]),
+        ("3", 1600, "rs16", "G", "C", "GT:PL", ["0/0:0,200,2000", "0/0:0,180,1800", "0/0:0,170,1700", "0/0:0,165,1650"]),
+    ]
+    probe = OUT + "/testdata/probe.vcf"
+    with open(probe, "w") as f:
+        f.write("##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n")
+        f.write("##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"PL\">\n##INFO=<ID=DP,Number=1,Type=Integer,Description=\"d\">\n")
+        f.write("##contig=<ID=1,length=249250621>\n##contig=<ID=X,length=155270560>\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tdau\tother\tpa\tson\tma\n")
+        for c, pos, rid, ref, alt, fmt, smp in rows:
+            pa, ma, son, dau = smp
+            f.write("\t".join([c, str(pos), rid, ref, alt, "50", "PASS", "DP=9", fmt, dau, "0/0:0,9,99", pa, son, ma]) + "\n")
+    noanchor = OUT + "/testdata/probe_noanchor.vcf"  # no ##INFO / ##contig anchors: fall-back header lines
+    with open(noanchor, "w") as f:
+        f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tpa\tma\tson\tdau\n")
+        for c, pos, rid, ref, alt, fmt, smp in rows[:3]:
+            f.write("\t".join([c, str(pos), rid, ref, alt, "50", "PASS", "DP=9", fmt] + smp) + "\n")
+    with open(OUT + "/testdata/probe.loc", "w") as f:
+        f.write("1\t100\nX\t300\n1\t600\n2\t1500\n5\t77\n")
+    probe_runs = {
+        "default": [], "a": ["-a"], "v": ["-v"], "mu0": ["-mRate", "0", "-a"],
+        "priors": ["-genoProbN", "0.9", "0.08", "0.02", "-genoProbK", "0.3", "0.4", "0.3", "-genoProbXN", "0.97", "0.03",
+                   "-genoProbXK", "0.6", "0.4", "-mRate", "1e-3", "-LRC", "0.9"],
+        "loc": ["-l", OUT + "/testdata/probe.loc"],
+    }
+    for tag, extra in probe_runs.items():
+        subprocess.check_call([oracle.REF_CLI, "vcf", "-vcfFile", probe, "-pedFile", probe_ped, "-output",
+                               "%s/ref_cli/probe_%s.vcf" % (OUT, tag), "-method", "1"] + extra, stdout=subprocess.DEVNULL)
+    subprocess.check_call([oracle.REF_CLI, "vcf", "-vcfFile", noanchor, "-pedFile", probe_ped, "-output",
+                           OUT + "/ref_cli/probe_noanchor.vcf"], stdout=subprocess.DEVNULL)
+    # LK files in the three transformed likelihood types, from the first 20 loftest rows
+    with open(OUT + "/testdata/loftest.txt") as f:
+        lk_lines = [l.rstrip("\n") for l in f][:21]
+    conv = {"log10": lambda x: "%.10g" % math.log10(x), "ln": lambda x: "%.10g" % math.log(x),
+            "PS": lambda x: "%.10g" % (-10 * math.log10(x))}
+    for typ, fn in conv.items():
+        path = "%s/testdata/lk_%s.txt" % (OUT, typ)
+        with open(path, "w") as f:
+            f.write(lk_lines[0] + "\n")
+            for l in lk_lines[1:]:
+                f.write("\t".join(",".join(fn(float(x)) for x in cell.split(",")) if cell else "" for cell in l.split("\t")) + "\n")
+        subprocess.check_call([oracle.REF_CLI, "LK", "-lkFile", path, "-pedFile", OUT + "/testdata/fam04.ped", "-output",
+                               "%s/ref_cli/lk_%s_fam04.txt" % (OUT, typ), "-lkType", typ], stdout=subprocess.DEVNULL)
+
     # ---- raw fp64 pins ---------------------------------------------------
     vcf, lkf = {}, {}
     for k in range(1, 7):

@@ -32,33 +32,39 @@ def emulate_site(plan, model, lk, fl):
     """-> unnormalised marginals [N,3] and the number of configurations visited."""
     N, L, A, J = plan["N"], plan["L"], plan["A"], plan["J"]
     TL, ns, tab = plan["team_lanes"], plan["n_slots"], plan["iter_tab"]
-    nA, nB = plan["nA"], plan["nB"]
-    laneoff = np.array(plan["laneoff"], dtype=np.int64).reshape(ns, TL)
-    joff = np.array(plan["joff"], dtype=np.int64).reshape(3, ns, tab)
+    nA, nB, stride, ss = plan["nA"], plan["nB"], plan["row_stride"], plan["step_slots"]
+    assert nA + L + nB == ns and L + nB <= ss and stride >= ns and stride % 2 == 1
+    laneoff = np.array(plan["laneoff"], dtype=np.int64).reshape(TL, stride)
+    joff = np.array(plan["joff"], dtype=np.int64).reshape(3, tab, ss)
     jdig = np.array(plan["jdigits"], dtype=np.int64).reshape(3, tab)
     tcf = factor_tables(model)[fl]
     lkf = lk.reshape(-1)
+
+    def factor(pk, g9=0, g1=0):  # packed BYTE offsets -> table entry * likelihood entry
+        assert (pk & 0xFFFF) % 8 == 0 and (pk >> 16) % 8 == 0
+        return tcf[(pk & 0xFFFF) // 8 + g9] * lkf[(pk >> 16) // 8 + g1]
+
     cols = plan["cols"]
     red = np.zeros((cols, TL))
     visited = 0
     jn, jd = plan["jn"], plan["jd"]
+    low_dep = False
     for t in range(TL):
+        row = laneoff[t]
         pA = 1e7
         for s in range(nA):
-            pk = laneoff[s, t]
-            pA = pA * (tcf[pk & 0xFFFF] * lkf[pk >> 16])
+            pA = pA * factor(row[s])
         for j2, j1, j0 in itertools.product(range(jn[2]), range(jn[1]), range(jn[0])):
-            off = joff[0, :, j0] + joff[1, :, j1] + joff[2, :, j2]
+            rec = joff[0, j0] + joff[1, j1] + joff[2, j2]
+            low_dep = low_dep or bool(np.any(rec[:L]))
             pj = pA
-            for s in range(nA, nA + nB):
-                pk = laneoff[s, t] + off[s]
-                pj = pj * (tcf[pk & 0xFFFF] * lkf[pk >> 16])
+            for s in range(nB):
+                pj = pj * factor(row[nA + L + s] + rec[L + s])
             v = np.zeros((L, 3))
             for k in range(L):
-                pk = laneoff[nA + nB + k, t] + off[nA + nB + k]
-                ti, li = pk & 0xFFFF, pk >> 16
+                pk = row[nA + k] + rec[k]
                 for g in range(3):
-                    v[k, g] = tcf[ti + 9 * g] * lkf[li + g]
+                    v[k, g] = factor(pk, 9 * g, g)
             tot = 0.0
             for cfg in itertools.product(range(3), repeat=L):
                 w = pj
@@ -73,6 +79,7 @@ def emulate_site(plan, model, lk, fl):
                 for d in range(jd[lvl]):
                     g = (jdig[lvl, jl] >> (2 * d)) & 3
                     red[3 * L + 3 * (5 * lvl + d) + g, t] += tot
+    assert not (plan["low_invariant"] and low_dep), "plan claims low factors are step-invariant"
     bins = np.zeros((N, 3))
     for i in range(N):
         bk, bi = plan["bin_kind"][i], plan["bin_index"][i]

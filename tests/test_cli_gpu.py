@@ -1,0 +1,139 @@
+"""End-to-end text parity of bin/FamSeq (our CLI over the C ABI) with outputs of the compiled
+reference CLI (tests/golden/ref_cli, made by oracle/gen_golden.py).
+
+Comparison rule: header and pass-through lines byte-identical; in result
+lines every field identical except the Phred numbers, which the reference prints with 6
+significant digits: |a-b| <= 1e-5*max(|a|,|b|) or, for values < 1e-3 (the -10*log10(1-eps)
+rounding noise), <= 1e-6 absolute; `99999`, `NA` and the FGT call must match exactly."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "bin", "FamSeq")
+TD = os.path.join(ROOT, "tests", "golden", "testdata")
+REF = os.path.join(ROOT, "tests", "golden", "ref_cli")
+
+
+def run_cli(args, out):
+    p = subprocess.run([CLI] + args + ["-output", str(out)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return p.stdout
+
+
+def num_close(a, b):
+    if a == b:
+        return True
+    if "99999" in (a, b) or "NA" in (a, b):
+        return False
+    x, y = float(a), float(b)
+    if max(abs(x), abs(y)) < 1e-3:
+        return abs(x - y) <= 1e-6
+    return abs(x - y) <= 1e-5 * max(abs(x), abs(y))
+
+
+def assert_same_output(got_path, ref_path, tags=":GPP:FPP:FGT"):
+    got = open(got_path).read().split("\n")
+    ref = open(ref_path).read().split("\n")
+    assert len(got) == len(ref), "line count %d vs %d" % (len(got), len(ref))
+    n_results = 0
+    for ln, (g, r) in enumerate(zip(got, ref), 1):
+        if g == r:
+            n_results += tags in r or r.startswith("LK:GPP")
+            continue
+        gt, rt = g.split("\t"), r.split("\t")
+        assert len(gt) == len(rt), "line %d: column count" % ln
+        for a, b in zip(gt, rt):
+            if a == b:
+                continue
+            ga, rb = a.split(":"), b.split(":")
+            assert len(ga) == len(rb), "line %d: %r vs %r" % (ln, a, b)
+            for u, v in zip(ga, rb):
+                if u == v:
+                    continue
+                us, vs = u.split(","), v.split(",")
+                assert len(us) == len(vs) == 3, "line %d: %r vs %r" % (ln, a, b)
+                assert all(num_close(p, q) for p, q in zip(us, vs)), "line %d: %r vs %r" % (ln, a, b)
+        n_results += 1
+    return n_results
+
+
+@pytest.mark.parametrize("fam", range(1, 7))
+@pytest.mark.parametrize("tag,extra", [("v", ["-v"]), ("a", ["-a"]), ("plain", [])])
+def test_testdata_vcf(fam, tag, extra, tmp_path):
+    """TestData pedigrees x the reduced test.vcf (every PL-bearing line of TestData/test.vcf)."""
+    out = tmp_path / "o.vcf"
+    run_cli(["vcf", "-vcfFile", TD + "/test_subset.vcf", "-pedFile", "%s/fam%02d.ped" % (TD, fam), "-method", "1"] + extra, out)
+    assert assert_same_output(out, "%s/subset_fam%02d_%s.vcf" % (REF, fam, tag)) >= 12
+
+
+def test_baseline_config_1_result_lines(tmp_path):
+    """BASELINE config #1 (TestData/test.vcf + fam01.ped, -method 1 -v): the reference's 124 header
+    + 12 result lines, reproduced from the reduced VCF (which holds every computable line)."""
+    out = tmp_path / "o.vcf"
+    run_cli(["vcf", "-vcfFile", TD + "/test_subset.vcf", "-pedFile", TD + "/fam01.ped", "-v"], out)
+    assert assert_same_output(out, REF + "/full_fam01_v.vcf") == 12
+
+
+@pytest.mark.parametrize("fam", range(1, 7))
+def test_testdata_lk(fam, tmp_path):
+    out = tmp_path / "o.txt"
+    run_cli(["LK", "-lkFile", TD + "/loftest.txt", "-pedFile", "%s/fam%02d.ped" % (TD, fam)], out)
+    assert assert_same_output(out, "%s/loftest_fam%02d.txt" % (REF, fam)) == 100
+
+
+@pytest.mark.parametrize("typ", ["log10", "ln", "PS"])
+def test_lk_types(typ, tmp_path):
+    out = tmp_path / "o.txt"
+    run_cli(["LK", "-lkFile", "%s/lk_%s.txt" % (TD, typ), "-pedFile", TD + "/fam04.ped", "-lkType", typ], out)
+    assert assert_same_output(out, "%s/lk_%s_fam04.txt" % (REF, typ)) == 20
+
+
+PROBES = {
+    "default": [], "a": ["-a"], "v": ["-v"], "mu0": ["-mRate", "0", "-a"],
+    "priors": ["-genoProbN", "0.9", "0.08", "0.02", "-genoProbK", "0.3", "0.4", "0.3", "-genoProbXN", "0.97", "0.03",
+               "-genoProbXK", "0.6", "0.4", "-mRate", "1e-3", "-LRC", "0.9"],
+    "loc": ["-l", TD + "/probe.loc"],
+}
+
+
+@pytest.mark.parametrize("tag", sorted(PROBES))
+def test_probe_vcf(tag, tmp_path):
+    """chrX / Known / status 1 / status 2 (-mRate 0) / missing sample / GL / echo and drop rules /
+    location filter / custom priors, against the reference CLI's output."""
+    out = tmp_path / "o.vcf"
+    stdout = run_cli(["vcf", "-vcfFile", TD + "/probe.vcf", "-pedFile", TD + "/probe.ped"] + PROBES[tag], out)
+    assert_same_output(out, "%s/probe_%s.vcf" % (REF, tag))
+    ref_na = open("%s/probe_%s.vcf" % (REF, tag)).read().count(":NA:NA:NA\t") // 4
+    assert stdout.count("Warning: this variant hasn't been calculated") == ref_na
+    if tag == "mu0":
+        assert ref_na == 2  # POS 400 (single posterior fails) and POS 500 (all 81 terms are 0)
+
+
+def test_header_fallback_lines(tmp_path):
+    out = tmp_path / "o.vcf"
+    run_cli(["vcf", "-vcfFile", TD + "/probe_noanchor.vcf", "-pedFile", TD + "/probe.ped"], out)
+    assert_same_output(out, REF + "/probe_noanchor.vcf")
+    assert "calbulated by Single Method" in open(out).read()
+
+
+def test_small_batches_keep_output_order(tmp_path):
+    out = tmp_path / "o.vcf"
+    env = dict(os.environ, FAMSEQ_BATCH="3")
+    p = subprocess.run([CLI, "vcf", "-vcfFile", TD + "/test_subset.vcf", "-pedFile", TD + "/fam06.ped", "-a", "-output", str(out)],
+                       capture_output=True, text=True, env=env)
+    assert p.returncode == 0
+    assert_same_output(out, REF + "/subset_fam06_a.vcf")
+
+
+def test_usage_and_errors(tmp_path):
+    assert subprocess.run([CLI]).returncode == 255
+    assert subprocess.run([CLI, "bogus"], capture_output=True).returncode == 255
+    p = subprocess.run([CLI, "vcf", "-vcfFile", TD + "/probe.vcf", "-output", str(tmp_path / "x")], capture_output=True, text=True)
+    assert p.returncode == 255 and "ped file must be set" in p.stdout
+    p = subprocess.run([CLI, "vcf", "-vcfFile", TD + "/probe.vcf", "-pedFile", TD + "/probe.ped", "-output", str(tmp_path / "x"),
+                        "-method", "2"], capture_output=True, text=True)
+    assert p.returncode == 255 and "-method 1" in p.stdout

@@ -19,8 +19,8 @@ def plan_for(ped, **opt):
     return p
 
 
-@pytest.mark.parametrize("name,N,L,A,J,teams", [("ped5", 5, 3, 2, 0, 28), ("ped10", 10, 4, 5, 1, 1),
-                                                ("ped15", 15, 5, 5, 5, 1)])
+@pytest.mark.parametrize("name,N,L,A,J,teams", [("ped5", 5, 3, 2, 0, 28), ("ped10", 10, 4, 4, 2, 3),
+                                                ("ped15", 15, 5, 4, 6, 3)])
 def test_benchmark_pedigree_plans(name, N, L, A, J, teams):
     p = plan_for(fs.synthetic_pedigree(name))
     assert (p["N"], p["L"], p["A"], p["J"]) == (N, L, A, J)
