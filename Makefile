@@ -7,7 +7,7 @@ CSRC := famseq_amd/csrc
 LIB := famseq_amd/lib/libfamseq_hip.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-result
 
-SRCS := $(CSRC)/bn_kernel.hip $(CSRC)/capi.cpp $(CSRC)/plan.cpp $(CSRC)/model.cpp
+SRCS := $(CSRC)/bn_kernel.hip $(CSRC)/capi.cpp $(CSRC)/plan.cpp $(CSRC)/model.cpp $(CSRC)/jit.cpp $(CSRC)/elim_codegen.cpp
 OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 
 CLI := bin/FamSeq
@@ -31,7 +31,7 @@ build/stub/libamdhip64.so:
 $(LIB): $(OBJS) build/stub/libamdhip64.so
 	@mkdir -p famseq_amd/lib
 	g++ -shared -fPIC -o $@ $(OBJS) -Wl,--no-as-needed -Lbuild/stub -lamdhip64 -Wl,--as-needed \
-	    -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
+	    -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags -ldl
 
 # FamSeq-compatible command line (host C++ only; talks to the GPU through the C ABI)
 $(CLI): $(CSRC)/host/famseq_cli.cpp include/famseq_hip.h $(LIB)

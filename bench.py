@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--option", action="append", default=[], help="famseq_set_option key=value (tuning)")
+    ap.add_argument("--engine", default="enum", choices=["enum", "elim"],
+                    help="engine of the headline number (enum = the 3^N enumeration the metric is defined on)")
+    ap.add_argument("--no-elim", action="store_true", help="skip the side measurement of the elimination engine")
     return ap.parse_args()
 
 
@@ -152,6 +155,8 @@ def main():
     for kv in a.option:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
+    if a.engine == "elim":
+        ctx.set_option("engine", fs.ENGINE_ELIM)
     plan = ctx.plan()
 
     # this rank's own range of the seeded stream, generated straight into HBM
@@ -171,17 +176,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        ev[k][0].record(stream)
-        step()
-        ev[k][1].record(stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    def timed_steps():
+        for _ in range(a.warmup):
+            step()
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            ev[k][0].record(stream)
+            step()
+            ev[k][1].record(stream)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ev
+
+    elapsed, ev = timed_steps()
     if world > 1:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -227,6 +235,21 @@ def main():
                           "unit": "Tops/s", "frac": S * ops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
                           "ops_per_site": ops, "configs_per_s": S * 3 ** n / (kernel_ms * 1e-3)},
         }
+        if a.engine == "enum" and not a.no_elim and plan["elim_supported"]:
+            # side measurement: the exact sum-product engine on the same resident batch
+            ref_post = post.clone()
+            ctx.set_option("engine", fs.ENGINE_ELIM)
+            e_el, ev_el = timed_steps()
+            k_ms = sum(s.elapsed_time(e) for s, e in ev_el) / a.steps
+            dev = float(((post - ref_post).abs() / ref_post.clamp_min(1e-300)).max().item())
+            out["elim_engine"] = {
+                "value": S * a.steps / e_el, "unit": "sites/s (this rank)", "kernel": "famseq_elim (generated per pedigree)",
+                "kernel_ms": k_ms, "max_rel_dev_vs_enum": dev,
+                "roofline": {"bound": "hbm", "achieved": S * bytes_per_site / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": S * bytes_per_site / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "read_frac": S * (24 * n + 1) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+            ctx.set_option("engine", fs.ENGINE_ENUM)
+            del ref_post
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ped, cfg, a.cpu_seconds, n)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]

@@ -26,6 +26,7 @@ MAXN = 20
 
 ST_OK, ST_SINGLE_FAIL, ST_BN_FAIL, ST_SHORTCUT = 0, 1, 2, 0x80
 FLAG_KNOWN, FLAG_CHRX = 1, 2
+ENGINE_ENUM, ENGINE_ELIM = 0, 1
 
 
 class FamseqError(RuntimeError):

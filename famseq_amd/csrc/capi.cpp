@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "bn_kernel.h"
+#include "elim_codegen.h"
+#include "jit.h"
 #include "famseq_hip.h"
 #include "plan.h"
 
@@ -31,6 +33,9 @@ struct famseq_ctx {
   int blocks_per_cu = 0;
   int64_t grid_override = 0;
   int64_t chunk_sites = 0;
+  int engine = FAMSEQ_ENGINE_ENUM;
+  JitKernel elim{};      // generated sum-product kernel (engine = FAMSEQ_ENGINE_ELIM)
+  int elim_blocks_per_cu = 0;
   // device constants
   uint32_t *d_img = nullptr;
   double *d_tc = nullptr;
@@ -123,6 +128,47 @@ int grid_for(const famseq_ctx *c, int64_t n_sites) {
   return (int)std::max<int64_t>(1, std::min(passes, resident));
 }
 
+// Generate, compile (or fetch) and load the elimination kernel for this model.
+int load_elim(famseq_ctx *c) {
+  if (c->elim.fn || (c->device < 0 && !c->elim.path.empty())) return 0;
+  std::string why;
+  if (!elim_supported(c->model, &why)) return fail(c, FAMSEQ_E_ARG, "elimination engine: " + why);
+  try {
+    if (c->device < 0) {  // plan-only ctx: generate and compile into the cache (this is how build() pre-builds)
+      c->elim.path = jit_compile(elim_source(c->model));
+      return 0;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->elim = jit_load(elim_source(c->model), "famseq_elim");
+  } catch (const std::exception &e) {
+    return fail(c, FAMSEQ_E_HIP, e.what());
+  }
+  int nb = 0;
+  HIP_TRY(c, hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->elim.fn, elim_block_threads(c->model), 0));
+  c->elim_blocks_per_cu = nb > 0 ? nb : 1;
+  return 0;
+}
+
+hipError_t launch_elim(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, double *d_post,
+                       double *d_single, uint8_t *d_status, hipStream_t stream) {
+  const int bt = elim_block_threads(c->model);
+  const int64_t chunks = (n_sites + bt - 1) / bt;
+  int64_t resident = c->grid_override > 0 ? c->grid_override : int64_t(c->n_cus) * c->elim_blocks_per_cu;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min(chunks, resident));
+  long ns = (long)n_sites;
+  double lc = c->model.lc;
+  const double *tc = c->d_tc;
+  void *args[] = {&d_lk, &d_flags, &d_post, &d_single, &d_status, &ns, &tc, &lc};
+  return hipModuleLaunchKernel(c->elim.fn, grid, 1, 1, (unsigned)bt, 1, 1, 0, stream, args, nullptr);
+}
+
+hipError_t launch_engine(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, double *d_post,
+                         double *d_single, uint8_t *d_status, hipStream_t stream) {
+  if (c->engine == FAMSEQ_ENGINE_ELIM) return launch_elim(c, n_sites, d_lk, d_flags, d_post, d_single, d_status, stream);
+  return launch_bn_enum(c->plan, c->kp, grid_for(c, n_sites), c->d_img, c->d_tc, n_sites, d_lk, d_flags, d_post,
+                        d_single, d_status, stream);
+}
+
 }  // namespace
 
 extern "C" int famseq_device_count(void) {
@@ -189,6 +235,7 @@ extern "C" void famseq_destroy(famseq_ctx *c) {
     free_slots(c);
     if (c->d_img) (void)hipFree(c->d_img);
     if (c->d_tc) (void)hipFree(c->d_tc);
+    jit_unload(c->elim);
     for (int s = 0; s < famseq_ctx::kSlots; ++s)
       if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
   }
@@ -205,6 +252,15 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
   else if (k == "low_members") c->opt.low_members = (int)value;
   else if (k == "block_threads") c->opt.block_threads = (int)value;
   else if (k == "grid_blocks") { c->grid_override = value; return 0; }
+  else if (k == "engine") {
+    if (value != FAMSEQ_ENGINE_ENUM && value != FAMSEQ_ENGINE_ELIM) return fail(c, FAMSEQ_E_ARG, "engine must be 0 (enum) or 1 (elim)");
+    if (value == FAMSEQ_ENGINE_ELIM) {
+      const int rc = load_elim(c);
+      if (rc != 0) return rc;
+    }
+    c->engine = (int)value;
+    return 0;
+  }
   else if (k == "chunk_sites") { c->chunk_sites = value; free_slots(c); return 0; }
   else return fail(c, FAMSEQ_E_ARG, "unknown option " + k);
   c->plan_dirty = true;
@@ -223,7 +279,9 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
   if (!c) return "{}";
   c->json = c->plan.json();
   c->json.pop_back();
-  c->json += ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
+  c->json += ",\"engine\":" + std::to_string(c->engine) + ",\"elim_supported\":" +
+             std::string(elim_supported(c->model, nullptr) ? "1" : "0") + ",\"elim_code_object\":\"" + c->elim.path +
+             "\",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
              ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + "}";
   return c->json.c_str();
 }
@@ -235,8 +293,7 @@ extern "C" int famseq_bn_batch_device(famseq_ctx *c, int64_t n_sites, const doub
   if (n_sites < 0 || (n_sites > 0 && (!d_lk || !d_post))) return fail(c, FAMSEQ_E_ARG, "bad batch arguments");
   if (n_sites == 0) return 0;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, launch_bn_enum(c->plan, c->kp, grid_for(c, n_sites), c->d_img, c->d_tc, n_sites, d_lk, d_flags, d_post,
-                            d_single, d_status, static_cast<hipStream_t>(stream)));
+  HIP_TRY(c, launch_engine(c, n_sites, d_lk, d_flags, d_post, d_single, d_status, static_cast<hipStream_t>(stream)));
   return 0;
 }
 
@@ -269,9 +326,8 @@ extern "C" int famseq_bn_batch(famseq_ctx *c, int64_t n_sites, const double *lk,
     HIP_TRY(c, hipStreamSynchronize(st));  // the slot's previous chunk has fully drained
     HIP_TRY(c, hipMemcpyAsync(c->d_lk[s], lk + lo * 3 * c->plan.N, n * row, hipMemcpyHostToDevice, st));
     if (flags) HIP_TRY(c, hipMemcpyAsync(c->d_flags[s], flags + lo, n, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, launch_bn_enum(c->plan, c->kp, grid_for(c, n), c->d_img, c->d_tc, n, c->d_lk[s],
-                              flags ? c->d_flags[s] : nullptr, c->d_post[s], post_single ? c->d_single[s] : nullptr,
-                              status ? c->d_status[s] : nullptr, st));
+    HIP_TRY(c, launch_engine(c, n, c->d_lk[s], flags ? c->d_flags[s] : nullptr, c->d_post[s],
+                             post_single ? c->d_single[s] : nullptr, status ? c->d_status[s] : nullptr, st));
     HIP_TRY(c, hipMemcpyAsync(post + lo * 3 * c->plan.N, c->d_post[s], n * row, hipMemcpyDeviceToHost, st));
     if (post_single)
       HIP_TRY(c, hipMemcpyAsync(post_single + lo * 3 * c->plan.N, c->d_single[s], n * row, hipMemcpyDeviceToHost, st));

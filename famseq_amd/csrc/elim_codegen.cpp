@@ -1,0 +1,297 @@
+// elim_codegen.cpp — generates the exact sum-product ("elimination") kernel for one pedigree.
+//
+// Same marginals as the 3^N enumeration of family::calPostProbBN
+// (/root/reference/src/family.cpp:882-954, :990-1120), computed by message passing on the
+// pedigree's factor graph instead of visiting every joint genotype:
+//   variable nodes = members, factor nodes = nuclear families (mother, father, children) with
+//   Phi_F = prod_children T_c[g_c | g_m, g_f]; member-local factors are prior*lk for founders
+//   and lk for the others (exactly the indProb terms of family.cpp:899-909).
+// On a loop-free pedigree (the domain of the reference's own Elston-Stewart -method 2,
+// family.cpp:1126-1403) the factor graph is a forest and two messages per edge give every
+// marginal exactly: O(27 N) flops per site instead of 2*3^N, which makes the path HBM-bound.
+// Pedigrees with marriage loops are rejected here; the enumeration engine handles them.
+//
+// The kernel is emitted as straight-line HIP for this one topology: every index is a literal,
+// so a lane keeps a whole site (likelihoods, messages) in registers; one lane = one site.
+// Arithmetic: fp64; sums of products written as explicit FMA chains; the single posterior, the
+// shortcut vote and the failure rules are the same statements as in bn_kernel.hip (bit-identical
+// to the CPU reference).  One member per connected component carries the reference's 1e7 scale.
+#include "elim_codegen.h"
+
+#include <functional>
+#include <map>
+#include <numeric>
+#include <sstream>
+#include <stdexcept>
+#include <vector>
+
+namespace famseq {
+
+namespace {
+
+struct Family {
+  int mo, fa;
+  std::vector<int> kids;
+};
+
+struct Graph {
+  int N = 0;
+  std::vector<Family> fam;
+  std::vector<std::vector<int>> nb;  // member -> adjacent families
+  std::vector<int> scaled;           // one member per connected component
+};
+
+bool build_graph(const famseq_model &m, Graph &g, std::string *why) {
+  g.N = m.n_members;
+  std::map<std::pair<int, int>, int> idx;
+  g.nb.assign(g.N, {});
+  for (int i = 0; i < g.N; ++i) {
+    if (m.mother[i] < 0) continue;
+    const auto key = std::make_pair(m.mother[i], m.father[i]);
+    auto it = idx.find(key);
+    if (it == idx.end()) {
+      it = idx.emplace(key, (int)g.fam.size()).first;
+      g.fam.push_back({key.first, key.second, {}});
+      if (key.first == key.second) {
+        if (why) *why = "a member's mother and father are the same individual";
+        return false;
+      }
+      g.nb[key.first].push_back(it->second);
+      g.nb[key.second].push_back(it->second);
+    }
+    g.fam[it->second].kids.push_back(i);
+    g.nb[i].push_back(it->second);
+  }
+  // forest check on the bipartite member/family graph
+  std::vector<int> parent(g.N + g.fam.size());
+  std::iota(parent.begin(), parent.end(), 0);
+  std::function<int(int)> find = [&](int x) { return parent[x] == x ? x : parent[x] = find(parent[x]); };
+  for (size_t f = 0; f < g.fam.size(); ++f) {
+    std::vector<int> mem = {g.fam[f].mo, g.fam[f].fa};
+    mem.insert(mem.end(), g.fam[f].kids.begin(), g.fam[f].kids.end());
+    for (int p : mem) {
+      const int a = find(p), b = find(g.N + (int)f);
+      if (a == b) {
+        if (why) *why = "the pedigree has a loop (consanguinity or marriage loop); use the enumeration engine";
+        return false;
+      }
+      parent[a] = b;
+    }
+  }
+  std::vector<char> seen(parent.size(), 0);
+  for (int p = 0; p < g.N; ++p) {
+    const int r = find(p);
+    if (!seen[r]) {
+      seen[r] = 1;
+      g.scaled.push_back(p);
+    }
+  }
+  return true;
+}
+
+class Emitter {
+ public:
+  Emitter(const famseq_model &m, const Graph &g) : m_(m), g_(g) {}
+
+  std::string body() {
+    for (int p = 0; p < g_.N; ++p) marginal(p);
+    return o_.str();
+  }
+
+ private:
+  const famseq_model &m_;
+  const Graph &g_;
+  std::ostringstream o_;
+  std::map<std::string, bool> done_;
+
+  static std::string num(int x) { return std::to_string(x); }
+  bool once(const std::string &key) {
+    if (done_.count(key)) return false;
+    done_[key] = true;
+    return true;
+  }
+  int kind(int p) const {
+    const bool male = m_.gender[p] == 1;
+    return m_.mother[p] < 0 ? (male ? 0 : 1) : (male ? 2 : 3);
+  }
+  std::string T(int child, int gc, int gm, int gf) const {
+    return "tcf[" + num(kind(child) * 27 + 9 * gc + 3 * gm + gf) + "]";
+  }
+
+  // member-local factor c{p}_g
+  std::string loc(int p) {
+    const std::string n = "c" + num(p);
+    if (once(n)) {
+      bool scale = false;
+      for (int s : g_.scaled) scale |= s == p;
+      for (int g = 0; g < 3; ++g) {
+        std::string e = "l" + num(p) + "_" + num(g);
+        if (m_.mother[p] < 0) e = "(tcf[" + num(kind(p) * 27 + 9 * g) + "] * " + e + ")";
+        if (scale) e = "(10000000.0 * " + e + ")";
+        o_ << "      const double " << n << "_" << g << " = " << e << ";\n";
+      }
+    }
+    return n;
+  }
+
+  // member -> family message v{p}f{F}_g = local * prod of the other families' messages
+  std::string var2fac(int p, int F) {
+    const std::string n = "v" + num(p) + "f" + num(F);
+    if (once(n)) {
+      std::vector<std::string> in = {loc(p)};
+      for (int F2 : g_.nb[p])
+        if (F2 != F) in.push_back(fac2var(F2, p));
+      for (int g = 0; g < 3; ++g) {
+        o_ << "      const double " << n << "_" << g << " = ";
+        for (size_t k = 0; k < in.size(); ++k) o_ << (k ? " * " : "") << in[k] << "_" << g;
+        o_ << ";\n";
+      }
+    }
+    return n;
+  }
+
+  // child summary a{F}k{c}_{gm}{gf} = sum_gc T_c[gc|gm,gf] * v{c}f{F}_gc
+  std::string child_sum(int F, int c) {
+    const std::string n = "a" + num(F) + "k" + num(c);
+    if (once(n)) {
+      const std::string x = var2fac(c, F);
+      for (int gm = 0; gm < 3; ++gm)
+        for (int gf = 0; gf < 3; ++gf)
+          o_ << "      const double " << n << "_" << gm << gf << " = __builtin_fma(" << T(c, 2, gm, gf) << ", " << x
+             << "_2, __builtin_fma(" << T(c, 1, gm, gf) << ", " << x << "_1, " << T(c, 0, gm, gf) << " * " << x
+             << "_0));\n";
+    }
+    return n;
+  }
+
+  // family -> member message f{F}v{t}_g
+  std::string fac2var(int F, int t) {
+    const std::string n = "f" + num(F) + "v" + num(t);
+    if (!once(n)) return n;
+    const Family &fam = g_.fam[F];
+    std::vector<std::string> sums;
+    for (int c : fam.kids)
+      if (c != t) sums.push_back(child_sum(F, c));
+    const std::string xm = t == fam.mo ? "" : var2fac(fam.mo, F);
+    const std::string xf = t == fam.fa ? "" : var2fac(fam.fa, F);
+    // C_{gm}{gf}: product of the other children's summaries, times the parents' messages present
+    const std::string C = n + "w";
+    for (int gm = 0; gm < 3; ++gm)
+      for (int gf = 0; gf < 3; ++gf) {
+        std::vector<std::string> terms;
+        if (!xm.empty()) terms.push_back(xm + "_" + num(gm));
+        if (!xf.empty()) terms.push_back(xf + "_" + num(gf));
+        for (const std::string &s : sums) terms.push_back(s + "_" + num(gm) + num(gf));
+        o_ << "      const double " << C << "_" << gm << gf << " = ";
+        if (terms.empty()) o_ << "1.0";
+        for (size_t k = 0; k < terms.size(); ++k) o_ << (k ? " * " : "") << terms[k];
+        o_ << ";\n";
+      }
+    for (int g = 0; g < 3; ++g) {
+      o_ << "      const double " << n << "_" << g << " = ";
+      if (t == fam.mo) {
+        o_ << "(" << C << "_" << g << "0 + " << C << "_" << g << "1) + " << C << "_" << g << "2";
+      } else if (t == fam.fa) {
+        o_ << "(" << C << "_0" << g << " + " << C << "_1" << g << ") + " << C << "_2" << g;
+      } else {
+        std::string e;
+        for (int gm = 0; gm < 3; ++gm)
+          for (int gf = 0; gf < 3; ++gf) {
+            const std::string term = T(t, g, gm, gf) + ", " + C + "_" + num(gm) + num(gf);
+            e = e.empty() ? "(" + T(t, g, gm, gf) + " * " + C + "_" + num(gm) + num(gf) + ")"
+                          : "__builtin_fma(" + term + ", " + e + ")";
+          }
+        o_ << e;
+      }
+      o_ << ";\n";
+    }
+    return n;
+  }
+
+  void marginal(int p) {
+    std::vector<std::string> in = {loc(p)};
+    for (int F : g_.nb[p]) in.push_back(fac2var(F, p));
+    for (int g = 0; g < 3; ++g) {
+      o_ << "      const double m" << p << "_" << g << " = ";
+      for (size_t k = 0; k < in.size(); ++k) o_ << (k ? " * " : "") << in[k] << "_" << g;
+      o_ << ";\n";
+    }
+    o_ << "      { const double s = (m" << p << "_0 + m" << p << "_1) + m" << p << "_2; if (s <= 0) bn_fail = true;\n"
+       << "        q[" << 3 * p << "] = m" << p << "_0 / s; q[" << 3 * p + 1 << "] = m" << p << "_1 / s; q[" << 3 * p + 2
+       << "] = m" << p << "_2 / s; }\n";
+  }
+};
+
+}  // namespace
+
+bool elim_supported(const famseq_model &m, std::string *why) {
+  Graph g;
+  return build_graph(m, g, why);
+}
+
+int elim_block_threads(const famseq_model &m) { return m.n_members <= 10 ? 256 : 128; }
+
+std::string elim_source(const famseq_model &m) {
+  Graph g;
+  std::string why;
+  if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);
+  const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1, BT = elim_block_threads(m);
+  std::ostringstream s;
+  s << "// generated by famseq_amd/csrc/elim_codegen.cpp for a " << N << "-member pedigree (" << g.fam.size()
+    << " nuclear families)\n"
+    << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
+    << "#define W3 " << W3 << "\n#define ROW " << ROW << "\n#define BT " << BT << "\n"
+    << "extern \"C\" __global__ __launch_bounds__(BT) void famseq_elim(const double *__restrict__ lk_g,\n"
+    << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
+    << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
+    << "  __shared__ double s_io[BT * ROW];  // one padded row per lane: conflict-free ds_read_b64\n"
+    << "  __shared__ double s_tc[432];\n"
+    << "  const int tid = threadIdx.x;\n"
+    << "  for (int i = tid; i < 432; i += BT) s_tc[i] = tc_g[i];\n"
+    << "  const long chunks = (n_sites + BT - 1) / BT;\n"
+    << "  const long per_wg = (chunks + gridDim.x - 1) / gridDim.x;\n"
+    << "  const long c_lo = (long)blockIdx.x * per_wg, c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;\n"
+    << "  const double kNaN = __builtin_nan(\"\");\n"
+    << "  double *row = s_io + tid * ROW;\n"
+    << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
+    << "    const long site0 = ch * BT;\n"
+    << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
+    << "    const int nel = ns * W3;\n"
+    << "    __syncthreads();\n"
+    << "    for (int e = tid; e < nel; e += BT) { const int si = e / W3; s_io[si * ROW + (e - si * W3)] = lk_g[site0 * W3 + e]; }\n"
+    << "    __syncthreads();\n"
+    << "    const int fl = (tid < ns && flags_g) ? (flags_g[site0 + tid] & 3) : 0;\n"
+    << "    const double *tcf = s_tc + fl * 108;\n";
+  for (int p = 0; p < N; ++p)
+    for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = row[" << 3 * p + gt << "];\n";
+  s << "    double q[W3];\n    bool single_fail = false, full = false, bn_fail = false;\n";
+  // single posterior (family.cpp:1426-1445) and shortcut vote (:767-789): same statements as bn_kernel.hip
+  for (int p = 0; p < N; ++p) {
+    const int fk = m.gender[p] == 1 ? 0 : 1;
+    s << "    { const double p0 = l" << p << "_0 * tcf[" << fk * 27 << "], p1 = l" << p << "_1 * tcf[" << fk * 27 + 9
+      << "], p2 = l" << p << "_2 * tcf[" << fk * 27 + 18 << "];\n"
+      << "      const double s = (p0 + p1) + p2; if (s <= 0) single_fail = true;\n"
+      << "      q[" << 3 * p << "] = p0 / s; q[" << 3 * p + 1 << "] = p1 / s; q[" << 3 * p + 2 << "] = p2 / s; }\n";
+    if (m.sequenced[p])
+      s << "    { double big = 0; if (big < l" << p << "_0) big = l" << p << "_0; if (big < l" << p << "_1) big = l" << p
+        << "_1; if (big < l" << p << "_2) big = l" << p << "_2;\n"
+        << "      const double sum = (l" << p << "_0 + l" << p << "_1) + l" << p << "_2; big = big / sum; if (big < lc) full = true; }\n";
+  }
+  s << "    __syncthreads();  // every lane holds its row in registers: the rows become the output stage\n"
+    << "#pragma unroll\n    for (int k = 0; k < W3; ++k) row[k] = single_fail ? kNaN : q[k];\n"
+    << "    __syncthreads();\n"
+    << "    if (single_g) for (int e = tid; e < nel; e += BT) { const int si = e / W3; single_g[site0 * W3 + e] = s_io[si * ROW + (e - si * W3)]; }\n"
+    << "    if (full && !single_fail) {\n"
+    << Emitter(m, g).body()
+    << "    }\n"
+    << "    __syncthreads();  // single rows have been stored\n"
+    << "    const bool dead = single_fail || (full && bn_fail);\n"
+    << "#pragma unroll\n    for (int k = 0; k < W3; ++k) row[k] = dead ? kNaN : q[k];\n"
+    << "    __syncthreads();\n"
+    << "    for (int e = tid; e < nel; e += BT) { const int si = e / W3; post_g[site0 * W3 + e] = s_io[si * ROW + (e - si * W3)]; }\n"
+    << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
+    << "  }\n}\n";
+  return s.str();
+}
+
+}  // namespace famseq

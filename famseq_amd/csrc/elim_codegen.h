@@ -1,0 +1,19 @@
+// elim_codegen.h — source generator of the exact sum-product ("elimination") engine.
+#ifndef FAMSEQ_ELIM_CODEGEN_H_
+#define FAMSEQ_ELIM_CODEGEN_H_
+
+#include <string>
+
+#include "famseq_hip.h"
+
+namespace famseq {
+
+// Loop-free pedigree (member/nuclear-family graph is a forest)?  `why` receives the reason if not.
+bool elim_supported(const famseq_model &m, std::string *why);
+// HIP source of `extern "C" __global__ famseq_elim(lk, flags, post, single, status, n_sites, tc, lc)`
+// specialised for the model's topology, sexes and sequenced set.  Throws if unsupported.
+std::string elim_source(const famseq_model &m);
+int elim_block_threads(const famseq_model &m);
+
+}  // namespace famseq
+#endif

@@ -1,0 +1,31 @@
+// jit.h — per-pedigree kernel specialisation: HIP source -> code object -> hipFunction.
+//
+// Some engines of this library are generated as straight-line HIP for one pedigree (its
+// topology fixes every index, so all per-site state lives in registers).  The source is
+// compiled with hipcc --genco for gfx950 and cached on disk by content hash:
+//   <dir of libfamseq_hip.so>/kernels/<hash>.hsaco      (in-tree: prebuilt objects travel
+//   with the library)  or  $FAMSEQ_KERNEL_CACHE  or  /tmp/famseq_kernels_<uid>.
+// Compiler: $FAMSEQ_HIPCC or /opt/rocm/bin/hipcc.
+#ifndef FAMSEQ_JIT_H_
+#define FAMSEQ_JIT_H_
+
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+
+namespace famseq {
+
+struct JitKernel {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+  std::string path;  // code object on disk
+};
+
+// Compile (or fetch from the cache) and load on the current device.  Throws std::runtime_error.
+JitKernel jit_load(const std::string &source, const std::string &entry);
+// Compile into the cache without loading (no GPU needed); returns the code-object path.
+std::string jit_compile(const std::string &source);
+void jit_unload(JitKernel &k);
+
+}  // namespace famseq
+#endif

@@ -46,6 +46,11 @@ extern "C" {
 #define FAMSEQ_FLAG_KNOWN 1
 #define FAMSEQ_FLAG_CHRX 2
 
+/* engines (famseq_set_option "engine") */
+#define FAMSEQ_ENGINE_ENUM 0 /* 3^N joint-genotype enumeration: any pedigree (the reference's -method 1 algorithm) */
+#define FAMSEQ_ENGINE_ELIM 1 /* exact sum-product on the pedigree's factor graph: same marginals in O(27 N) per
+                                site; loop-free pedigrees only; kernel generated and compiled per pedigree */
+
 /* error codes (negative returns) */
 #define FAMSEQ_E_ARG (-1)      /* bad argument / model rejected */
 #define FAMSEQ_E_NODEVICE (-2) /* no usable gfx950 device, or ctx created without one */
@@ -102,6 +107,9 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *   "block_threads" workgroup size (multiple of 64, <= 768)
  *   "grid_blocks"   persistent grid size (0 = auto: CUs x resident blocks)
  *   "chunk_sites"   host-staging chunk of famseq_bn_batch (0 = auto)
+ *   "engine"        FAMSEQ_ENGINE_ENUM (default) or FAMSEQ_ENGINE_ELIM; selecting ELIM generates the
+ *                   kernel for this pedigree, compiles it with hipcc (cached on disk) and fails with
+ *                   FAMSEQ_E_ARG on a pedigree with loops
  * Returns 0 or FAMSEQ_E_ARG. */
 int famseq_set_option(famseq_ctx *ctx, const char *key, int64_t value);
 

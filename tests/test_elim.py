@@ -1,0 +1,40 @@
+"""Elimination engine, host side (no GPU): the per-pedigree kernel source is generated and
+compiles for gfx950; pedigrees with loops are rejected (they stay on the enumeration engine)."""
+import os
+
+import pytest
+
+import famseq_amd as fs
+
+
+def cousins_marry():
+    #  1,2 -> 3,4 ; 3x5 -> 7 ; 4x6 -> 8 ; 7x8 -> 9  (first-cousin marriage: a loop)
+    ids = [1, 2, 3, 4, 5, 6, 7, 8, 9]
+    mids = [0, 0, 2, 2, 0, 0, 5, 4, 8]
+    fids = [0, 0, 1, 1, 0, 0, 3, 6, 7]
+    gen = [1, 2, 1, 2, 2, 1, 1, 2, 1]
+    return fs.Pedigree(ids, mids, fids, gen, ["s%d" % i for i in ids])
+
+
+@pytest.mark.parametrize("name", ["ped5", "ped10"])
+def test_generated_kernel_compiles(name):
+    ctx = fs.Context(fs.make_model(fs.synthetic_pedigree(name)), device=-1)
+    assert ctx.plan()["elim_supported"] == 1
+    ctx.set_option("engine", fs.ENGINE_ELIM)
+    p = ctx.plan()
+    assert p["engine"] == fs.ENGINE_ELIM
+    assert p["elim_code_object"].endswith(".hsaco") and os.path.getsize(p["elim_code_object"]) > 1000
+    ctx.close()
+
+
+def test_loop_pedigree_is_rejected():
+    ped = cousins_marry()
+    ped.relations()
+    ctx = fs.Context(fs.make_model(ped), device=-1)
+    assert ctx.plan()["elim_supported"] == 0
+    with pytest.raises(fs.FamseqError, match="loop"):
+        ctx.set_option("engine", fs.ENGINE_ELIM)
+    assert ctx.plan()["engine"] == fs.ENGINE_ENUM  # stays on enumeration
+    with pytest.raises(fs.FamseqError):
+        ctx.set_option("engine", 7)
+    ctx.close()

@@ -38,6 +38,57 @@ def test_fixture_parity(c):
     ctx.close()
 
 
+def elim_ctx(c):
+    ctx = fs.Context(fs.make_model(c.pedigree(), **c.consts))
+    if not ctx.plan()["elim_supported"]:
+        ctx.close()
+        pytest.skip("pedigree has loops: enumeration engine only")
+    ctx.set_option("engine", fs.ENGINE_ELIM)
+    return ctx
+
+
+@pytest.mark.parametrize("c", CASES, ids=repr)
+def test_fixture_parity_elimination_engine(c):
+    """The exact sum-product engine (kernel generated per pedigree) against the same
+    compiled-reference fixtures, same bars."""
+    ctx = elim_ctx(c)
+    check(c, *ctx.bn_batch(c.lk, c.flags))
+    ctx.close()
+
+
+def test_elimination_equals_enumeration_on_a_loop_free_20_member_pedigree():
+    """N = 20 is out of reach for the oracle (3^20 configs/site) but not for the GPU: both
+    engines must agree with each other there, and with the oracle on N = 13."""
+    ids, mids, fids, gen = [1, 2], [0, 0], [0, 0], [1, 2]
+    while len(ids) < 20:  # a line of descent: each child marries a founder
+        child, spouse = len(ids) + 1, len(ids) + 2
+        male_child = (len(ids) // 2) % 2 == 0
+        ids += [child, spouse]
+        prev_child, prev_spouse = ids[-4], ids[-3]
+        mo = prev_child if gen[-2] == 2 else prev_spouse
+        fa = prev_spouse if gen[-2] == 2 else prev_child
+        mids += [mo, 0]
+        fids += [fa, 0]
+        gen += [1, 2] if male_child else [2, 1]
+    ped = fs.Pedigree(ids, mids, fids, gen, ["s%d" % i for i in ids])
+    mo, fa = ped.relations()
+    for n in (13, 20):
+        sub = fs.Pedigree(ids[:n], mids[:n], fids[:n], gen[:n], ped.names[:n])
+        mo, fa = sub.relations()
+        lk, flags = fs.synth.gen_batch(mo, fa, 4 if n == 13 else 2, 51)
+        flags[0] |= 2
+        en = fs.Context(fs.make_model(sub))
+        el = fs.Context(fs.make_model(sub), engine=fs.ENGINE_ELIM)
+        a, b = en.bn_batch(lk, flags), el.bn_batch(lk, flags)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1])
+        np.testing.assert_allclose(a[0], b[0], rtol=RTOL)
+        if n == 13:
+            ref = oracle.OracleModel(sub.ids, sub.mids, sub.fids, sub.genders).bn_batch(lk, flags, threads=4)
+            np.testing.assert_allclose(b[0], ref[0], rtol=RTOL)
+        en.close()
+        el.close()
+
+
 TILINGS = [dict(fixed_digits=0), dict(fixed_digits=1), dict(fixed_digits=2, low_members=1), dict(low_members=2),
            dict(fixed_digits=3, low_members=2), dict(fixed_digits=6), dict(block_threads=512), dict(block_threads=64)]
 
@@ -119,15 +170,16 @@ def test_device_pointer_entry_matches_host_entry():
     ctx.close()
 
 
+@pytest.mark.parametrize("engine", [fs.ENGINE_ENUM, fs.ENGINE_ELIM], ids=["enum", "elim"])
 @pytest.mark.parametrize("name,cfg,n_sites", [("ped5", 1, 200_000), ("ped10", 2, 20_000)])
-def test_full_size_properties(name, cfg, n_sites):
+def test_full_size_properties(name, cfg, n_sites, engine):
     """Size-independent properties on large seeded batches (BASELINE configs' shape):
     rows are distributions, the run is bit-reproducible, the answer does not depend on
     batch position or on how the batch is sharded, and a sampled subset matches the oracle."""
     ped = fs.synthetic_pedigree(name)
     mo, fa = ped.relations()
     lk, flags = fs.synth.gen_batch(mo, fa, n_sites, cfg)
-    ctx = fs.Context(fs.make_model(ped))
+    ctx = fs.Context(fs.make_model(ped), engine=engine)
     post, single, st = ctx.bn_batch(lk, flags)
     assert np.all(st == 0)  # generator guarantees no shortcut, no failure
     assert np.all(post >= 0) and np.allclose(post.sum(axis=2), 1.0, rtol=0, atol=1e-12)
