@@ -217,7 +217,7 @@ class Emitter {
       o_ << ";\n";
     }
     o_ << "      { const double s = (m" << p << "_0 + m" << p << "_1) + m" << p << "_2; if (s <= 0) bn_fail = true;\n"
-       << "        q[" << 3 * p << "] = m" << p << "_0 / s; q[" << 3 * p + 1 << "] = m" << p << "_1 / s; q[" << 3 * p + 2
+       << "        row[" << 3 * p << "] = m" << p << "_0 / s; row[" << 3 * p + 1 << "] = m" << p << "_1 / s; row[" << 3 * p + 2
        << "] = m" << p << "_2 / s; }\n";
   }
 };
@@ -241,7 +241,7 @@ std::string elim_source(const famseq_model &m) {
     << " nuclear families)\n"
     << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
     << "#define W3 " << W3 << "\n#define ROW " << ROW << "\n#define BT " << BT << "\n"
-    << "extern \"C\" __global__ __launch_bounds__(BT) void famseq_elim(const double *__restrict__ lk_g,\n"
+    << "extern \"C\" __global__ __launch_bounds__(BT, BT / 128) void famseq_elim(const double *__restrict__ lk_g,\n"
     << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
     << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
     << "  __shared__ double s_io[BT * ROW];  // one padded row per lane: conflict-free ds_read_b64\n"
@@ -264,29 +264,28 @@ std::string elim_source(const famseq_model &m) {
     << "    const double *tcf = s_tc + fl * 108;\n";
   for (int p = 0; p < N; ++p)
     for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = row[" << 3 * p + gt << "];\n";
-  s << "    double q[W3];\n    bool single_fail = false, full = false, bn_fail = false;\n";
+  s << "    bool single_fail = false, full = false, bn_fail = false;\n"
+    << "    __syncthreads();  // every lane holds its row in registers: the rows become the output stage\n";
   // single posterior (family.cpp:1426-1445) and shortcut vote (:767-789): same statements as bn_kernel.hip
   for (int p = 0; p < N; ++p) {
     const int fk = m.gender[p] == 1 ? 0 : 1;
     s << "    { const double p0 = l" << p << "_0 * tcf[" << fk * 27 << "], p1 = l" << p << "_1 * tcf[" << fk * 27 + 9
       << "], p2 = l" << p << "_2 * tcf[" << fk * 27 + 18 << "];\n"
       << "      const double s = (p0 + p1) + p2; if (s <= 0) single_fail = true;\n"
-      << "      q[" << 3 * p << "] = p0 / s; q[" << 3 * p + 1 << "] = p1 / s; q[" << 3 * p + 2 << "] = p2 / s; }\n";
+      << "      row[" << 3 * p << "] = p0 / s; row[" << 3 * p + 1 << "] = p1 / s; row[" << 3 * p + 2 << "] = p2 / s; }\n";
     if (m.sequenced[p])
       s << "    { double big = 0; if (big < l" << p << "_0) big = l" << p << "_0; if (big < l" << p << "_1) big = l" << p
         << "_1; if (big < l" << p << "_2) big = l" << p << "_2;\n"
         << "      const double sum = (l" << p << "_0 + l" << p << "_1) + l" << p << "_2; big = big / sum; if (big < lc) full = true; }\n";
   }
-  s << "    __syncthreads();  // every lane holds its row in registers: the rows become the output stage\n"
-    << "#pragma unroll\n    for (int k = 0; k < W3; ++k) row[k] = single_fail ? kNaN : q[k];\n"
+  s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
     << "    __syncthreads();\n"
     << "    if (single_g) for (int e = tid; e < nel; e += BT) { const int si = e / W3; single_g[site0 * W3 + e] = s_io[si * ROW + (e - si * W3)]; }\n"
+    << "    __syncthreads();  // single rows are stored; sites that enumerate overwrite theirs with the marginals\n"
     << "    if (full && !single_fail) {\n"
     << Emitter(m, g).body()
+    << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
     << "    }\n"
-    << "    __syncthreads();  // single rows have been stored\n"
-    << "    const bool dead = single_fail || (full && bn_fail);\n"
-    << "#pragma unroll\n    for (int k = 0; k < W3; ++k) row[k] = dead ? kNaN : q[k];\n"
     << "    __syncthreads();\n"
     << "    for (int e = tid; e < nel; e += BT) { const int si = e / W3; post_g[site0 * W3 + e] = s_io[si * ROW + (e - si * W3)]; }\n"
     << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"

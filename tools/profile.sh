@@ -1,0 +1,26 @@
+#!/bin/bash
+# tools/profile.sh TAG [bench args...] — rocprofv3 evidence for one bench configuration, on the GPU box.
+#   kernel-trace + stats of the full-size run, then PMC passes (separate, as gfx950's TCC slots
+#   require; never combined with API tracing) at 1 M sites.  Results land in gpurun_out/TAG/;
+#   tools/pmc_summary.py condenses them; copy what is to be judged into profiles/.
+set -u
+TAG=$1; shift
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/kt.log 2>&1
+echo "kernel-trace rc=$?"
+for c in FETCH_SIZE WRITE_SIZE \
+  "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" \
+  "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64" \
+  "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  tag=$(echo $c | cut -d" " -f1)
+  timeout -k 10 170 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$tag -- python3 $R/bench.py --no-cpu-baseline --sites 1000000 --steps 2 --warmup 1 "$@" > $O/pmc_$tag.log 2>&1
+  echo "$tag rc=$?"
+done
+cd $R
+python3 tools/pmc_summary.py $O
+cp $O/kt/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+head -3 $O/kernel_stats.csv | cut -c1-220
