@@ -33,7 +33,7 @@ WORKLOADS = {  # name -> (BASELINE.json config number, default sites per GPU)
     "ped15": (4, 20_000),
 }
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_VALU_PEAK_TOPS = 39.3   # 78.6 TFLOP/s FMA-counted / 2: this path has no fusable mul+add
+FP64_VALU_PEAK_TOPS = 39.3   # fp64 vector instructions-lanes/s: 78.6 TFLOP/s (FMA = 2 flops) / 2
 
 
 def parse():
@@ -52,11 +52,10 @@ def parse():
     return ap.parse_args()
 
 
-def fp64_ops_per_site(plan):
-    """fp64 instructions the low tree executes per site: one FMA per configuration at the leaf
-    level plus a multiply and an FMA per internal edge (3^L + 2*(3^L - 3)/2 per lane step)."""
-    L, A, J = plan["L"], plan["A"], plan["J"]
-    return (3 ** L + (3 ** L - 3)) * 3 ** (A + J)
+def fp64_ops_per_site(plan, n):
+    """Enumeration roofline: the 3^N joint weights must each be formed and added once — one fp64
+    FMA per configuration is the least an enumeration can execute."""
+    return 3 ** n
 
 
 def host_cores():
@@ -215,7 +214,14 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("sites_per_launch"):
                 traffic = tj["bytes_per_launch"] * S / tj["sites_per_launch"]
-        ops = fp64_ops_per_site(plan)
+        ops = fp64_ops_per_site(plan, n)
+        plan = ctx.plan()  # after the run: tells which enumeration kernel served the batch
+        if a.engine == "elim":
+            kernel_name = "famseq_elim (generated per pedigree)"
+        elif plan["enum_lane_code_object"] and not plan["enum_lane_failed"] and plan["enum_impl"] != 0:
+            kernel_name = "famseq_enum_lane (generated per pedigree, lane per site)"
+        else:
+            kernel_name = "bn_enum_kernel<%d> (team per site)" % plan["L"]
         out = {
             "metric": "variant sites/sec (whole node), %d-member pedigree BN posterior" % n,
             "value": value, "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -228,12 +234,13 @@ def main():
                                                      "lds_bytes", "blocks_per_cu")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "bn_enum_kernel<%d>" % plan["L"], "kernel_ms": kernel_ms,
+                         "kernel": kernel_name, "kernel_ms": kernel_ms,
                          "bytes_per_site": bytes_per_site,
                          "read_GBps": S * (24 * n + 1) / (kernel_ms * 1e-3) / 1e9},
             "fp64_valu": {"achieved": S * ops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TOPS,
-                          "unit": "Tops/s", "frac": S * ops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
-                          "ops_per_site": ops, "configs_per_s": S * 3 ** n / (kernel_ms * 1e-3)},
+                          "unit": "T fp64 FMA/s (one per joint configuration)",
+                          "frac": S * ops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
+                          "configs_per_site": ops, "configs_per_s": S * 3 ** n / (kernel_ms * 1e-3)},
         }
         if a.engine == "enum" and not a.no_elim and plan["elim_supported"]:
             # side measurement: the exact sum-product engine on the same resident batch

@@ -16,6 +16,7 @@
 
 #include "bn_kernel.h"
 #include "elim_codegen.h"
+#include "enum_codegen.h"
 #include "jit.h"
 #include "famseq_hip.h"
 #include "plan.h"
@@ -36,6 +37,14 @@ struct famseq_ctx {
   int engine = FAMSEQ_ENGINE_ENUM;
   JitKernel elim{};      // generated sum-product kernel (engine = FAMSEQ_ENGINE_ELIM)
   int elim_blocks_per_cu = 0;
+  // enumeration engine: the team-per-site kernel is compiled into the library; the lane-per-site
+  // kernel is generated per pedigree.  enum_impl: -1 auto (lane for large batches), 0 team, 1 lane
+  int enum_impl = -1;
+  JitKernel lane{};
+  int lane_blocks_per_cu = 0;
+  bool lane_failed = false;
+  std::string lane_error;
+  int64_t lane_min_sites = 16384;
   // device constants
   uint32_t *d_img = nullptr;
   double *d_tc = nullptr;
@@ -149,22 +158,56 @@ int load_elim(famseq_ctx *c) {
   return 0;
 }
 
-hipError_t launch_elim(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, double *d_post,
-                       double *d_single, uint8_t *d_status, hipStream_t stream) {
-  const int bt = elim_block_threads(c->model);
+// Generate/compile/load the lane-per-site enumeration kernel (once).  Returns false when it is
+// unavailable (no compiler at run time, ...): the compiled-in team kernel then serves all batches.
+bool load_lane(famseq_ctx *c) {
+  if (c->lane.fn) return true;
+  if (c->lane_failed) return false;
+  try {
+    const std::string src = enumgen_source(c->model);
+    if (c->device < 0) {
+      c->lane.path = jit_compile(src);
+      return true;
+    }
+    c->lane = jit_load(src, "famseq_enum_lane");
+    int nb = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->lane.fn, enumgen_block_threads(c->model), 0) != hipSuccess)
+      nb = 1;
+    c->lane_blocks_per_cu = nb > 0 ? nb : 1;
+    return true;
+  } catch (const std::exception &e) {
+    c->lane_failed = true;
+    c->lane_error = e.what();
+    return false;
+  }
+}
+
+hipError_t launch_generated(famseq_ctx *c, hipFunction_t fn, int bt, int blocks_per_cu, int64_t n_sites,
+                            const double *d_lk, const uint8_t *d_flags, double *d_post, double *d_single,
+                            uint8_t *d_status, hipStream_t stream) {
   const int64_t chunks = (n_sites + bt - 1) / bt;
-  int64_t resident = c->grid_override > 0 ? c->grid_override : int64_t(c->n_cus) * c->elim_blocks_per_cu;
+  int64_t resident = c->grid_override > 0 ? c->grid_override : int64_t(c->n_cus) * blocks_per_cu;
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min(chunks, resident));
   long ns = (long)n_sites;
   double lc = c->model.lc;
   const double *tc = c->d_tc;
   void *args[] = {&d_lk, &d_flags, &d_post, &d_single, &d_status, &ns, &tc, &lc};
-  return hipModuleLaunchKernel(c->elim.fn, grid, 1, 1, (unsigned)bt, 1, 1, 0, stream, args, nullptr);
+  return hipModuleLaunchKernel(fn, grid, 1, 1, (unsigned)bt, 1, 1, 0, stream, args, nullptr);
+}
+
+hipError_t launch_elim(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, double *d_post,
+                       double *d_single, uint8_t *d_status, hipStream_t stream) {
+  return launch_generated(c, c->elim.fn, elim_block_threads(c->model), c->elim_blocks_per_cu, n_sites, d_lk, d_flags,
+                          d_post, d_single, d_status, stream);
 }
 
 hipError_t launch_engine(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, double *d_post,
                          double *d_single, uint8_t *d_status, hipStream_t stream) {
   if (c->engine == FAMSEQ_ENGINE_ELIM) return launch_elim(c, n_sites, d_lk, d_flags, d_post, d_single, d_status, stream);
+  const bool want_lane = c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites);
+  if (want_lane && load_lane(c))
+    return launch_generated(c, c->lane.fn, enumgen_block_threads(c->model), c->lane_blocks_per_cu, n_sites, d_lk, d_flags,
+                            d_post, d_single, d_status, stream);
   return launch_bn_enum(c->plan, c->kp, grid_for(c, n_sites), c->d_img, c->d_tc, n_sites, d_lk, d_flags, d_post,
                         d_single, d_status, stream);
 }
@@ -236,6 +279,7 @@ extern "C" void famseq_destroy(famseq_ctx *c) {
     if (c->d_img) (void)hipFree(c->d_img);
     if (c->d_tc) (void)hipFree(c->d_tc);
     jit_unload(c->elim);
+    jit_unload(c->lane);
     for (int s = 0; s < famseq_ctx::kSlots; ++s)
       if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
   }
@@ -252,6 +296,13 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
   else if (k == "low_members") c->opt.low_members = (int)value;
   else if (k == "block_threads") c->opt.block_threads = (int)value;
   else if (k == "grid_blocks") { c->grid_override = value; return 0; }
+  else if (k == "enum_impl") {
+    if (value < -1 || value > 1) return fail(c, FAMSEQ_E_ARG, "enum_impl must be -1 (auto), 0 (team kernel) or 1 (lane kernel)");
+    if (value == 1 && !load_lane(c)) return fail(c, FAMSEQ_E_HIP, "lane-per-site kernel unavailable: " + c->lane_error);
+    c->enum_impl = (int)value;
+    return 0;
+  }
+  else if (k == "lane_min_sites") { c->lane_min_sites = value; return 0; }
   else if (k == "engine") {
     if (value != FAMSEQ_ENGINE_ENUM && value != FAMSEQ_ENGINE_ELIM) return fail(c, FAMSEQ_E_ARG, "engine must be 0 (enum) or 1 (elim)");
     if (value == FAMSEQ_ENGINE_ELIM) {
@@ -281,7 +332,8 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
   c->json.pop_back();
   c->json += ",\"engine\":" + std::to_string(c->engine) + ",\"elim_supported\":" +
              std::string(elim_supported(c->model, nullptr) ? "1" : "0") + ",\"elim_code_object\":\"" + c->elim.path +
-             "\",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
+             "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + c->lane.path +
+             "\",\"enum_lane_failed\":" + std::string(c->lane_failed ? "1" : "0") + ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
              ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + "}";
   return c->json.c_str();
 }

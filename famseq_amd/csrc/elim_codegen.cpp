@@ -231,17 +231,19 @@ bool elim_supported(const famseq_model &m, std::string *why) {
 
 int elim_block_threads(const famseq_model &m) { return m.n_members <= 10 ? 256 : 128; }
 
-std::string elim_source(const famseq_model &m) {
-  Graph g;
-  std::string why;
-  if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);
-  const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1, BT = elim_block_threads(m);
+// The part every generated engine shares: I/O staging through padded LDS rows, the single
+// posterior, the shortcut vote and the status byte.  `body` runs for sites that need the full
+// computation; it reads l<p>_<g> and tcf[...] and must write the normalised marginals to
+// row[0..W3) and set bn_fail on a row sum <= 0.
+std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
+                         const std::string &body, int bt, int min_waves) {
+  const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1;
   std::ostringstream s;
-  s << "// generated by famseq_amd/csrc/elim_codegen.cpp for a " << N << "-member pedigree (" << g.fam.size()
-    << " nuclear families)\n"
+  s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
-    << "#define W3 " << W3 << "\n#define ROW " << ROW << "\n#define BT " << BT << "\n"
-    << "extern \"C\" __global__ __launch_bounds__(BT, BT / 128) void famseq_elim(const double *__restrict__ lk_g,\n"
+    << "#define W3 " << W3 << "\n#define ROW " << ROW << "\n#define BT " << bt << "\n"
+    << "extern \"C\" __global__ __launch_bounds__(BT, " << min_waves << ") void " << entry
+    << "(const double *__restrict__ lk_g,\n"
     << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
     << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
     << "  __shared__ double s_io[BT * ROW];  // one padded row per lane: conflict-free ds_read_b64\n"
@@ -281,9 +283,9 @@ std::string elim_source(const famseq_model &m) {
   s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
     << "    __syncthreads();\n"
     << "    if (single_g) for (int e = tid; e < nel; e += BT) { const int si = e / W3; single_g[site0 * W3 + e] = s_io[si * ROW + (e - si * W3)]; }\n"
-    << "    __syncthreads();  // single rows are stored; sites that enumerate overwrite theirs with the marginals\n"
+    << "    __syncthreads();  // single rows are stored; sites that need the full computation overwrite theirs\n"
     << "    if (full && !single_fail) {\n"
-    << Emitter(m, g).body()
+    << body
     << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
     << "    }\n"
     << "    __syncthreads();\n"
@@ -291,6 +293,16 @@ std::string elim_source(const famseq_model &m) {
     << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
     << "  }\n}\n";
   return s.str();
+}
+
+std::string elim_source(const famseq_model &m) {
+  Graph g;
+  std::string why;
+  if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);
+  const int bt = elim_block_threads(m);
+  return kernel_shell(m, "famseq_elim",
+                      "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families", Emitter(m, g).body(),
+                      bt, bt / 128);
 }
 
 }  // namespace famseq

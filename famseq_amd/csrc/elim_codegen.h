@@ -15,5 +15,9 @@ bool elim_supported(const famseq_model &m, std::string *why);
 std::string elim_source(const famseq_model &m);
 int elim_block_threads(const famseq_model &m);
 
+// Shared shell of the generated kernels (see elim_codegen.cpp).
+std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
+                         const std::string &body, int bt, int min_waves);
+
 }  // namespace famseq
 #endif

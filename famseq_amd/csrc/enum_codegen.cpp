@@ -1,0 +1,269 @@
+// enum_codegen.cpp — generates the lane-per-site 3^N enumeration kernel for one pedigree.
+//
+// Same computation as bn_enum_kernel (bn_kernel.hip) and as the reference's odometer
+// (/root/reference/src/family.cpp:894-941, :1014-1106): every one of the 3^N joint genotype
+// weights 1e7 * prod_m f_m is formed and added to the marginals.  What changes is the mapping:
+// here ONE LANE owns a whole site, so there is no cross-lane reduction, no workgroup barrier in
+// the hot loop and no per-step table traffic — everything a site needs lives in registers.
+//   * "outer" members (ancestors) are walked by ordinary nested loops; the loop digits are the
+//     same in every lane, so their table offsets are scalar;
+//   * the last <= 6 members in descent order ("unrolled" set U, closed under children) form a
+//     fully unrolled block of 3^|U| configurations whose factor tables (indexed by the unrolled
+//     parents' digits) are rebuilt in registers once per outer step;
+//   * inside the block prefix products are shared level by level, the deepest member's marginal
+//     takes one FMA per configuration, and every other member receives block sums.
+// The generic team-per-site kernel remains the fallback (small batches, no compiler at run time).
+#include "enum_codegen.h"
+
+#include <algorithm>
+#include <sstream>
+#include <stdexcept>
+#include <vector>
+
+#include "elim_codegen.h"
+
+namespace famseq {
+
+namespace {
+
+std::string num(int x) { return std::to_string(x); }
+
+struct Shape {
+  int N = 0;
+  std::vector<int> outer, unrolled;  // both in parents-before-children order
+  std::vector<int> upos;             // member -> level in `unrolled` or -1
+};
+
+int kind_of(const famseq_model &m, int p) {
+  const bool male = m.gender[p] == 1;
+  return m.mother[p] < 0 ? (male ? 0 : 1) : (male ? 2 : 3);
+}
+
+Shape choose_shape(const famseq_model &m, int cap) {
+  const int N = m.n_members;
+  std::vector<std::vector<int>> kids(N);
+  for (int i = 0; i < N; ++i)
+    if (m.mother[i] >= 0) {
+      kids[m.mother[i]].push_back(i);
+      kids[m.father[i]].push_back(i);
+    }
+  // depth = longest chain of ancestors; sorting by it gives a parents-before-children order
+  std::vector<int> depth(N, 0);
+  for (int pass = 0; pass < N; ++pass)
+    for (int i = 0; i < N; ++i)
+      if (m.mother[i] >= 0) depth[i] = std::max(depth[i], 1 + std::max(depth[m.mother[i]], depth[m.father[i]]));
+  std::vector<int> order(N);
+  for (int i = 0; i < N; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth[a] < depth[b]; });
+  std::vector<char> inU(N, 0);
+  int nu = 0;
+  auto table_doubles = [&]() {
+    int t = 0;
+    for (int i = 0; i < N; ++i)
+      if (inU[i]) {
+        int e = 3;
+        if (m.mother[i] >= 0) e *= (inU[m.mother[i]] ? 3 : 1) * (inU[m.father[i]] ? 3 : 1);
+        t += e;
+      }
+    return t;
+  };
+  // children first: a member may join U only when all its children already have
+  for (int k = N - 1; k >= 0 && nu < cap; --k) {
+    const int i = order[k];
+    bool ok = true;
+    for (int c : kids[i]) ok = ok && inU[c];
+    if (!ok) continue;
+    inU[i] = 1;
+    if (table_doubles() > 48) {  // register budget for the block's factor tables
+      inU[i] = 0;
+      continue;
+    }
+    ++nu;
+  }
+  Shape s;
+  s.N = N;
+  s.upos.assign(N, -1);
+  for (int i : order) {
+    if (inU[i]) {
+      s.upos[i] = (int)s.unrolled.size();
+      s.unrolled.push_back(i);
+    } else {
+      s.outer.push_back(i);
+    }
+  }
+  return s;
+}
+
+class Gen {
+ public:
+  Gen(const famseq_model &m, const Shape &s) : m_(m), s_(s), nu_((int)s.unrolled.size()) {}
+
+  std::string body() {
+    o_ << "      // outer (looped) members:";
+    for (int p : s_.outer) o_ << " " << p;
+    o_ << " | unrolled block:";
+    for (int p : s_.unrolled) o_ << " " << p;
+    o_ << " (" << pow3(nu_) << " configurations per outer step)\n";
+    for (int p = 0; p < s_.N; ++p)
+      o_ << "      double b" << p << "_0 = 0, b" << p << "_1 = 0, b" << p << "_2 = 0;\n";
+    o_ << "      const double P_root = 10000000.0;\n";  // family.cpp:911
+    outer_level(0, "P_root", "");
+    for (int p = 0; p < s_.N; ++p)
+      o_ << "      { const double s = (b" << p << "_0 + b" << p << "_1) + b" << p << "_2; if (s <= 0) bn_fail = true;\n"
+         << "        row[" << 3 * p << "] = b" << p << "_0 / s; row[" << 3 * p + 1 << "] = b" << p << "_1 / s; row["
+         << 3 * p + 2 << "] = b" << p << "_2 / s; }\n";
+    return o_.str();
+  }
+
+ private:
+  const famseq_model &m_;
+  const Shape &s_;
+  const int nu_;
+  std::ostringstream o_;
+  int uid_ = 0;
+
+  static int pow3(int e) {
+    int r = 1;
+    while (e-- > 0) r *= 3;
+    return r;
+  }
+
+  // table offset of member p's factor for child genotype expression `gc` ("2" or "g7"): literal
+  // part + digits of outer parents (runtime, uniform) — unrolled parents are added by the caller
+  std::string t_index(int p, const std::string &gc, int um, int uf) const {
+    std::string e = num(kind_of(m_, p) * 27) + " + 9 * " + gc;
+    if (m_.mother[p] >= 0) {
+      e += um >= 0 ? " + " + num(3 * um) : " + 3 * g" + num(m_.mother[p]);
+      e += uf >= 0 ? " + " + num(uf) : " + g" + num(m_.father[p]);
+    }
+    return e;
+  }
+
+  void outer_level(size_t k, const std::string &P, const std::string &acc_parent) {
+    if (k == s_.outer.size()) {
+      block(P, acc_parent);
+      return;
+    }
+    const int p = s_.outer[k];
+    const std::string g = "g" + num(p), ind(6 + 2 * k, ' ');
+    o_ << ind << "for (int " << g << " = 0; " << g << " < 3; ++" << g << ") {\n"
+       << ind << "  const double f" << p << " = tcf[" << t_index(p, g, -1, -1) << "] * (" << g << " == 0 ? l" << p
+       << "_0 : (" << g << " == 1 ? l" << p << "_1 : l" << p << "_2));\n"
+       << ind << "  const double P" << p << " = " << P << " * f" << p << ";\n"
+       << ind << "  double acc" << p << " = 0;\n";
+    outer_level(k + 1, "P" + num(p), "acc" + num(p));
+    o_ << ind << "  if (" << g << " == 0) b" << p << "_0 += acc" << p << "; else if (" << g << " == 1) b" << p
+       << "_1 += acc" << p << "; else b" << p << "_2 += acc" << p << ";\n";
+    if (!acc_parent.empty()) o_ << ind << "  " << acc_parent << " += acc" << p << ";\n";
+    o_ << ind << "}\n";
+  }
+
+  // name of table entry of unrolled level k for own digit g given the digits of the levels above
+  std::string w_name(int k, int g, const std::vector<int> &dig) const {
+    const int p = s_.unrolled[k];
+    std::string n = "w" + num(p) + "_" + num(g);
+    if (m_.mother[p] >= 0) {
+      if (s_.upos[m_.mother[p]] >= 0) n += "m" + num(dig[s_.upos[m_.mother[p]]]);
+      if (s_.upos[m_.father[p]] >= 0) n += "f" + num(dig[s_.upos[m_.father[p]]]);
+    }
+    return n;
+  }
+  std::string s_name(const std::vector<int> &dig) const {  // sum over the deepest member's own digit
+    const int p = s_.unrolled[nu_ - 1];
+    std::string n = "S" + num(p);
+    if (m_.mother[p] >= 0) {
+      if (s_.upos[m_.mother[p]] >= 0) n += "m" + num(dig[s_.upos[m_.mother[p]]]);
+      if (s_.upos[m_.father[p]] >= 0) n += "f" + num(dig[s_.upos[m_.father[p]]]);
+    }
+    return n;
+  }
+
+  void tables(const std::string &ind) {
+    for (int k = 0; k < nu_; ++k) {
+      const int p = s_.unrolled[k];
+      const bool has = m_.mother[p] >= 0;
+      const bool mu = has && s_.upos[m_.mother[p]] >= 0, fu = has && s_.upos[m_.father[p]] >= 0;
+      for (int gm = 0; gm < (mu ? 3 : 1); ++gm)
+        for (int gf = 0; gf < (fu ? 3 : 1); ++gf) {
+          std::string suffix;
+          if (mu) suffix += "m" + num(gm);
+          if (fu) suffix += "f" + num(gf);
+          for (int g = 0; g < 3; ++g)
+            o_ << ind << "const double w" << p << "_" << g << suffix << " = tcf["
+               << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * l" << p << "_" << g << ";\n";
+          if (k == nu_ - 1)
+            o_ << ind << "const double S" << p << suffix << " = (w" << p << "_0" << suffix << " + w" << p << "_1" << suffix
+               << ") + w" << p << "_2" << suffix << ";\n";
+        }
+    }
+  }
+
+  // emits level k of the unrolled block; returns the name of the subtree total
+  std::string level(int k, const std::string &P, std::vector<int> &dig, const std::string &ind) {
+    const int p = s_.unrolled[k];
+    if (k == nu_ - 1) {  // deepest member: one FMA per configuration
+      for (int g = 0; g < 3; ++g)
+        o_ << ind << "b" << p << "_" << g << " = __builtin_fma(" << P << ", " << w_name(k, g, dig) << ", b" << p << "_" << g
+           << ");\n";
+      o_ << ind << "asm volatile(\"\" : \"+v\"(b" << p << "_0), \"+v\"(b" << p << "_1), \"+v\"(b" << p << "_2), \"+v\"(" << P
+         << "));\n";
+      return "";
+    }
+    std::string subs[3];
+    for (int g = 0; g < 3; ++g) {
+      dig[k] = g;
+      const std::string pg = "p" + num(uid_++);
+      o_ << ind << "double " << pg << " = " << P << " * " << w_name(k, g, dig) << ";\n";
+      std::string sub;
+      if (k == nu_ - 2) {
+        sub = "s" + num(uid_++);
+        o_ << ind << "double " << sub << " = " << pg << " * " << s_name(dig) << ";\n"
+           << ind << "asm volatile(\"\" : \"+v\"(" << pg << "), \"+v\"(" << sub << "));\n";
+        level(k + 1, pg, dig, ind);
+      } else {
+        o_ << ind << "asm volatile(\"\" : \"+v\"(" << pg << "));\n";
+        sub = level(k + 1, pg, dig, ind);
+      }
+      o_ << ind << "b" << p << "_" << g << " += " << sub << ";\n"
+         << ind << "asm volatile(\"\" : \"+v\"(" << P << "), \"+v\"(b" << p << "_" << g << "), \"+v\"(" << sub << "));\n";
+      subs[g] = sub;
+    }
+    const std::string tot = "t" + num(uid_++);
+    o_ << ind << "double " << tot << " = (" << subs[0] << " + " << subs[1] << ") + " << subs[2] << ";\n";
+    return tot;
+  }
+
+  void block(const std::string &P, const std::string &acc_parent) {
+    const std::string ind(6 + 2 * s_.outer.size(), ' ');
+    o_ << ind << "{\n";
+    const std::string in2 = ind + "  ";
+    tables(in2);
+    std::vector<int> dig(nu_, 0);
+    std::string tot;
+    o_ << in2 << "double Pb = " << P << ";\n";
+    if (nu_ == 1) {
+      tot = "tb";
+      o_ << in2 << "const double tb = Pb * " << s_name(dig) << ";\n";
+      level(0, "Pb", dig, in2);
+    } else {
+      tot = level(0, "Pb", dig, in2);
+    }
+    if (!acc_parent.empty()) o_ << in2 << acc_parent << " += " << tot << ";\n";
+    o_ << ind << "}\n";
+  }
+};
+
+}  // namespace
+
+int enumgen_block_threads(const famseq_model &m) { return m.n_members <= 10 ? 256 : 128; }
+
+std::string enumgen_source(const famseq_model &m) {
+  const Shape s = choose_shape(m, 6);
+  if (s.unrolled.empty()) throw std::runtime_error("enumeration codegen: empty unrolled set");
+  const int bt = enumgen_block_threads(m);
+  std::string what = "3^N enumeration, lane per site, " + std::to_string(s.outer.size()) + " looped + " +
+                     std::to_string(s.unrolled.size()) + " unrolled members";
+  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s).body(), bt, bt / 128);
+}
+
+}  // namespace famseq

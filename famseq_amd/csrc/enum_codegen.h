@@ -1,0 +1,16 @@
+// enum_codegen.h — source generator of the lane-per-site 3^N enumeration kernel.
+#ifndef FAMSEQ_ENUM_CODEGEN_H_
+#define FAMSEQ_ENUM_CODEGEN_H_
+
+#include <string>
+
+#include "famseq_hip.h"
+
+namespace famseq {
+
+// HIP source of `extern "C" __global__ famseq_enum_lane(lk, flags, post, single, status, n_sites, tc, lc)`.
+std::string enumgen_source(const famseq_model &m);
+int enumgen_block_threads(const famseq_model &m);
+
+}  // namespace famseq
+#endif

@@ -9,6 +9,7 @@
 // bit-symmetric in (mother,father) and the posteriors are compared
 // against the reference CPU output.
 #include <cstring>
+#include <initializer_list>
 
 #include "famseq_hip.h"
 

@@ -107,6 +107,11 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *   "block_threads" workgroup size (multiple of 64, <= 768)
  *   "grid_blocks"   persistent grid size (0 = auto: CUs x resident blocks)
  *   "chunk_sites"   host-staging chunk of famseq_bn_batch (0 = auto)
+ *   "enum_impl"     which enumeration kernel serves FAMSEQ_ENGINE_ENUM: 0 = the team-per-site kernel
+ *                   compiled into the library (any batch size, any pedigree); 1 = the lane-per-site
+ *                   kernel generated and compiled for this pedigree (fastest on large batches);
+ *                   -1 (default) = lane kernel for batches of >= "lane_min_sites" (16384) sites when it
+ *                   can be built, team kernel otherwise
  *   "engine"        FAMSEQ_ENGINE_ENUM (default) or FAMSEQ_ENGINE_ELIM; selecting ELIM generates the
  *                   kernel for this pedigree, compiles it with hipcc (cached on disk) and fails with
  *                   FAMSEQ_E_ARG on a pedigree with loops

@@ -29,11 +29,13 @@ def check(c, post, single, st, ref=None):
     assert np.array_equal(post[short].view(np.uint64), rpost[short].view(np.uint64))
 
 
+@pytest.mark.parametrize("impl", [0, 1], ids=["team", "lane"])
 @pytest.mark.parametrize("c", CASES, ids=repr)
-def test_fixture_parity(c):
+def test_fixture_parity(c, impl):
     """Every compiled-reference fixture: 72 VCF site results, 600 LK rows, synthetic
-    autosome/chrX/custom-constant batches, failure and shortcut-boundary probes."""
-    ctx = fs.Context(fs.make_model(c.pedigree(), **c.consts))
+    autosome/chrX/custom-constant batches, failure and shortcut-boundary probes — through both
+    enumeration kernels (team-per-site compiled in, lane-per-site generated per pedigree)."""
+    ctx = fs.Context(fs.make_model(c.pedigree(), **c.consts), enum_impl=impl)
     check(c, *ctx.bn_batch(c.lk, c.flags))
     ctx.close()
 
@@ -77,11 +79,17 @@ def test_elimination_equals_enumeration_on_a_loop_free_20_member_pedigree():
         mo, fa = sub.relations()
         lk, flags = fs.synth.gen_batch(mo, fa, 4 if n == 13 else 2, 51)
         flags[0] |= 2
-        en = fs.Context(fs.make_model(sub))
+        en = fs.Context(fs.make_model(sub), enum_impl=0)
         el = fs.Context(fs.make_model(sub), engine=fs.ENGINE_ELIM)
         a, b = en.bn_batch(lk, flags), el.bn_batch(lk, flags)
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1])
         np.testing.assert_allclose(a[0], b[0], rtol=RTOL)
+        if n == 13:
+            ln = fs.Context(fs.make_model(sub), enum_impl=1)
+            c3 = ln.bn_batch(lk, flags)
+            assert np.array_equal(a[2], c3[2]) and np.array_equal(a[1], c3[1])
+            np.testing.assert_allclose(a[0], c3[0], rtol=RTOL)
+            ln.close()
         if n == 13:
             ref = oracle.OracleModel(sub.ids, sub.mids, sub.fids, sub.genders).bn_batch(lk, flags, threads=4)
             np.testing.assert_allclose(b[0], ref[0], rtol=RTOL)
@@ -100,7 +108,7 @@ def test_every_tiling_gives_the_same_answer(name, opt):
     (exercises multi-team workgroups, 1..3 nested iter levels, 729-lane teams)."""
     c = BY[name]
     try:
-        ctx = fs.Context(fs.make_model(c.pedigree(), **c.consts), **opt)
+        ctx = fs.Context(fs.make_model(c.pedigree(), **c.consts), enum_impl=0, **opt)
     except fs.FamseqError as e:
         pytest.skip("tiling not applicable: %s" % e)
     check(c, *ctx.bn_batch(c.lk, c.flags))
@@ -170,7 +178,7 @@ def test_device_pointer_entry_matches_host_entry():
     ctx.close()
 
 
-@pytest.mark.parametrize("engine", [fs.ENGINE_ENUM, fs.ENGINE_ELIM], ids=["enum", "elim"])
+@pytest.mark.parametrize("engine", [dict(enum_impl=0), dict(enum_impl=1), dict(engine=1)], ids=["team", "lane", "elim"])
 @pytest.mark.parametrize("name,cfg,n_sites", [("ped5", 1, 200_000), ("ped10", 2, 20_000)])
 def test_full_size_properties(name, cfg, n_sites, engine):
     """Size-independent properties on large seeded batches (BASELINE configs' shape):
@@ -179,7 +187,7 @@ def test_full_size_properties(name, cfg, n_sites, engine):
     ped = fs.synthetic_pedigree(name)
     mo, fa = ped.relations()
     lk, flags = fs.synth.gen_batch(mo, fa, n_sites, cfg)
-    ctx = fs.Context(fs.make_model(ped), engine=engine)
+    ctx = fs.Context(fs.make_model(ped), **engine)
     post, single, st = ctx.bn_batch(lk, flags)
     assert np.all(st == 0)  # generator guarantees no shortcut, no failure
     assert np.all(post >= 0) and np.allclose(post.sum(axis=2), 1.0, rtol=0, atol=1e-12)
@@ -205,12 +213,13 @@ def test_deep_enumeration_ped15_and_max_members():
     ped = fs.synthetic_pedigree("ped15")
     mo, fa = ped.relations()
     lk, flags = fs.synth.gen_batch(mo, fa, 2, 5)
-    ctx = fs.Context(fs.make_model(ped))
-    post, single, st = ctx.bn_batch(lk, flags)
     ref = oracle.OracleModel(ped.ids, ped.mids, ped.fids, ped.genders).bn_batch(lk, flags, threads=2)
-    assert np.array_equal(st, ref[2])
-    np.testing.assert_allclose(post, ref[0], rtol=RTOL)
-    ctx.close()
+    for impl in (0, 1):
+        ctx = fs.Context(fs.make_model(ped), enum_impl=impl)
+        post, single, st = ctx.bn_batch(lk, flags)
+        assert np.array_equal(st, ref[2])
+        np.testing.assert_allclose(post, ref[0], rtol=RTOL)
+        ctx.close()
     ids = list(range(1, 14))
     mids = [0, 0, 2, 0, 4, 0, 6, 0, 8, 0, 10, 0, 12]
     fids = [0, 0, 1, 0, 3, 0, 5, 0, 7, 0, 9, 0, 11]
@@ -219,7 +228,7 @@ def test_deep_enumeration_ped15_and_max_members():
     mo, fa = chain.relations()
     lk, flags = fs.synth.gen_batch(mo, fa, 3, 41)
     flags[1] |= 2
-    ctx = fs.Context(fs.make_model(chain))
+    ctx = fs.Context(fs.make_model(chain), enum_impl=0)
     assert ctx.plan()["jlevels"] == 2
     post, single, st = ctx.bn_batch(lk, flags)
     ref = oracle.OracleModel(ids, mids, fids, gen).bn_batch(lk, flags, threads=3)
