@@ -75,6 +75,11 @@ __device__ __forceinline__ void low_tree(double prefix, const double (&v)[L][3],
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, so each of
+// the barriers of a pass would wait for the wave's global stores to land; no global data is
+// handed between lanes here (staging loads are consumed by the ds_write that follows them).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int ipow3(int e) {
   int r = 1;
   for (int i = 0; i < e; ++i) r *= 3;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(768) void bn_enum_kernel(const KParams P, const uin
       s_fl[4 * e + 2] = 0;
       s_fl[4 * e + 3] = 0;
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase 1: single posterior (family.cpp:1426-1445) and shortcut vote (:767-789)
     for (int e = tid; e < nel; e += BT) {
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(768) void bn_enum_kernel(const KParams P, const uin
         if (big < P.lc) s_fl[4 * tm + 1] = 1;
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase 2: emit the single posterior; sites that do not enumerate are finished here
     for (int e = tid; e < nel; e += BT) {
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(768) void bn_enum_kernel(const KParams P, const uin
       }
       s_red[(P.cols - 1) * BT + tid] = total;
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase 4: cross-lane reduction, `parts` partial sums per marginal, fixed order
     {
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(768) void bn_enum_kernel(const KParams P, const uin
         s_part[w] = sum;
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase 5: marginals -> row sums -> normalise (family.cpp:943-954)
     for (int e = tid; e < nel; e += BT) {
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(768) void bn_enum_kernel(const KParams P, const uin
       if (s <= 0) s_fl[4 * tm + 3] = 1;
       s_bins[e] = b[g] / s;
     }
-    __syncthreads();
+    lds_barrier();
     for (int e = tid; e < nel; e += BT) {
       const int tm = e / W3;
       if (s_fl[4 * tm + 1] == 0 || s_fl[4 * tm + 2] != 0) continue;
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(768) void bn_enum_kernel(const KParams P, const uin
       for (int e = tid; e < nteam; e += BT)
         if (s_fl[4 * e + 1] != 0 && s_fl[4 * e + 2] == 0)
           status_g[site0 + e] = s_fl[4 * e + 3] ? FAMSEQ_ST_BN_FAIL : FAMSEQ_ST_OK;
-    __syncthreads();
+    lds_barrier();
   }
 }
 

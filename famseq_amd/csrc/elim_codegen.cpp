@@ -103,8 +103,13 @@ class Emitter {
   const Graph &g_;
   std::ostringstream o_;
   std::map<std::string, bool> done_;
+  int uid_ = 0;
 
   static std::string num(int x) { return std::to_string(x); }
+  // Compiler fence: LDS reads (table entries, likelihoods) may not be hoisted above it.  Without
+  // it hipcc front-loads the reads of the whole straight-line program and spills to scratch,
+  // which costs real HBM traffic in a kernel that is otherwise memory-bound.
+  void fence() { o_ << "      asm volatile(\"\" ::: \"memory\");\n"; }
   bool once(const std::string &key) {
     if (done_.count(key)) return false;
     done_[key] = true;
@@ -130,6 +135,7 @@ class Emitter {
         if (scale) e = "(10000000.0 * " + e + ")";
         o_ << "      const double " << n << "_" << g << " = " << e << ";\n";
       }
+      fence();
     }
     return n;
   }
@@ -150,17 +156,18 @@ class Emitter {
     return n;
   }
 
-  // child summary a{F}k{c}_{gm}{gf} = sum_gc T_c[gc|gm,gf] * v{c}f{F}_gc
+  // child summary a<id>_{gm}{gf} = sum_gc T_c[gc|gm,gf] * v{c}f{F}_gc.  Deliberately NOT memoised:
+  // a summary is needed by several messages of its family, and keeping 9 doubles per child alive
+  // across the whole program costs more (registers -> scratch -> HBM traffic) than recomputing
+  // 27 multiply-adds in a kernel whose vector ALU is mostly idle.
   std::string child_sum(int F, int c) {
-    const std::string n = "a" + num(F) + "k" + num(c);
-    if (once(n)) {
-      const std::string x = var2fac(c, F);
-      for (int gm = 0; gm < 3; ++gm)
-        for (int gf = 0; gf < 3; ++gf)
-          o_ << "      const double " << n << "_" << gm << gf << " = __builtin_fma(" << T(c, 2, gm, gf) << ", " << x
-             << "_2, __builtin_fma(" << T(c, 1, gm, gf) << ", " << x << "_1, " << T(c, 0, gm, gf) << " * " << x
-             << "_0));\n";
-    }
+    const std::string x = var2fac(c, F);
+    const std::string n = "a" + num(uid_++);
+    for (int gm = 0; gm < 3; ++gm)
+      for (int gf = 0; gf < 3; ++gf)
+        o_ << "      const double " << n << "_" << gm << gf << " = __builtin_fma(" << T(c, 2, gm, gf) << ", " << x
+           << "_2, __builtin_fma(" << T(c, 1, gm, gf) << ", " << x << "_1, " << T(c, 0, gm, gf) << " * " << x << "_0));\n";
+    fence();
     return n;
   }
 
@@ -205,6 +212,7 @@ class Emitter {
       }
       o_ << ";\n";
     }
+    fence();
     return n;
   }
 
@@ -217,8 +225,9 @@ class Emitter {
       o_ << ";\n";
     }
     o_ << "      { const double s = (m" << p << "_0 + m" << p << "_1) + m" << p << "_2; if (s <= 0) bn_fail = true;\n"
-       << "        row[" << 3 * p << "] = m" << p << "_0 / s; row[" << 3 * p + 1 << "] = m" << p << "_1 / s; row[" << 3 * p + 2
-       << "] = m" << p << "_2 / s; }\n";
+       << "        const double r = 1.0 / s;  // one division per row; this engine is not bit-ordered anyway\n"
+       << "        q[" << 3 * p << "] = m" << p << "_0 * r; q[" << 3 * p + 1 << "] = m" << p << "_1 * r; q[" << 3 * p + 2
+       << "] = m" << p << "_2 * r; }\n";
   }
 };
 
@@ -233,16 +242,34 @@ int elim_block_threads(const famseq_model &m) { return m.n_members <= 10 ? 256 :
 
 // The part every generated engine shares: I/O staging through padded LDS rows, the single
 // posterior, the shortcut vote and the status byte.  `body` runs for sites that need the full
-// computation; it reads l<p>_<g> and tcf[...] and must write the normalised marginals to
-// row[0..W3) and set bn_fail on a row sum <= 0.
+// computation; it reads l<p>_<g> and tcf[...], and must set bn_fail on a row sum <= 0.
+//   regs_l = true : the likelihood row is held in registers (l<p>_<g> are variables); the body
+//                   writes the normalised marginals to row[0..W3) (the row is free by then).
+//   regs_l = false: l<p>_<g> read the LDS row each time (short live ranges, no spills in the
+//                   message-passing code); the body writes the marginals to q[0..W3) and runs
+//                   BEFORE the single posterior takes over the row.
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
-                         const std::string &body, int bt, int min_waves) {
+                         const std::string &body, int bt, int min_waves, bool regs_l) {
   const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1;
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
     << "#define W3 " << W3 << "\n#define ROW " << ROW << "\n#define BT " << bt << "\n"
-    << "extern \"C\" __global__ __launch_bounds__(BT, " << min_waves << ") void " << entry
+    // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e.
+    // every barrier would wait for this wave's global stores to reach memory; nothing here hands
+    // global data between lanes, so only the LDS counter has to be zero.
+    << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
+    // element e = tid + k*BT of the chunk lives at LDS index a = (e / W3) * ROW + e % W3; the
+    // quotient and remainder are stepped incrementally instead of divided out per element.  The
+    // loop is fully unrolled so that all W3 global loads of a lane are in flight together (a
+    // rolled loop serialises W3 HBM latencies per chunk).
+    << "#define STAGE(stmt) { int e = tid, a = (tid / W3) * ROW + tid % W3, r = tid % W3; \\\n"
+    << "  _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { if (e < nel) { stmt; } e += BT; r += BT % W3; a += (BT / W3) * ROW + BT % W3; \\\n"
+    << "    if (r >= W3) { r -= W3; a += ROW - W3; } } }\n";
+  if (!regs_l)
+    for (int p = 0; p < N; ++p)
+      for (int gt = 0; gt < 3; ++gt) s << "#define l" << p << "_" << gt << " lrow[" << 3 * p + gt << "]\n";
+  s << "extern \"C\" __global__ __launch_bounds__(BT, " << min_waves << ") void " << entry
     << "(const double *__restrict__ lk_g,\n"
     << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
     << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
@@ -255,43 +282,73 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  const long c_lo = (long)blockIdx.x * per_wg, c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;\n"
     << "  const double kNaN = __builtin_nan(\"\");\n"
     << "  double *row = s_io + tid * ROW;\n"
+    << "  const volatile double *lrow = row;  // (regs_l = false) forces a fresh LDS read per use\n"
     << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
     << "    const long site0 = ch * BT;\n"
     << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
     << "    const int nel = ns * W3;\n"
-    << "    __syncthreads();\n"
-    << "    for (int e = tid; e < nel; e += BT) { const int si = e / W3; s_io[si * ROW + (e - si * W3)] = lk_g[site0 * W3 + e]; }\n"
-    << "    __syncthreads();\n"
+    << "    LDS_BARRIER();\n"
+    << "    STAGE(s_io[a] = lk_g[site0 * W3 + e]);\n"
+    << "    LDS_BARRIER();\n"
     << "    const int fl = (tid < ns && flags_g) ? (flags_g[site0 + tid] & 3) : 0;\n"
-    << "    const double *tcf = s_tc + fl * 108;\n";
-  for (int p = 0; p < N; ++p)
-    for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = row[" << 3 * p + gt << "];\n";
-  s << "    bool single_fail = false, full = false, bn_fail = false;\n"
-    << "    __syncthreads();  // every lane holds its row in registers: the rows become the output stage\n";
-  // single posterior (family.cpp:1426-1445) and shortcut vote (:767-789): same statements as bn_kernel.hip
-  for (int p = 0; p < N; ++p) {
-    const int fk = m.gender[p] == 1 ? 0 : 1;
-    s << "    { const double p0 = l" << p << "_0 * tcf[" << fk * 27 << "], p1 = l" << p << "_1 * tcf[" << fk * 27 + 9
-      << "], p2 = l" << p << "_2 * tcf[" << fk * 27 + 18 << "];\n"
-      << "      const double s = (p0 + p1) + p2; if (s <= 0) single_fail = true;\n"
-      << "      row[" << 3 * p << "] = p0 / s; row[" << 3 * p + 1 << "] = p1 / s; row[" << 3 * p + 2 << "] = p2 / s; }\n";
-    if (m.sequenced[p])
-      s << "    { double big = 0; if (big < l" << p << "_0) big = l" << p << "_0; if (big < l" << p << "_1) big = l" << p
-        << "_1; if (big < l" << p << "_2) big = l" << p << "_2;\n"
-        << "      const double sum = (l" << p << "_0 + l" << p << "_1) + l" << p << "_2; big = big / sum; if (big < lc) full = true; }\n";
+    << "    const double *tcf = s_tc + fl * 108;\n"
+    << "    bool single_fail = false, full = false, bn_fail = false;\n";
+  // statements of the single posterior (family.cpp:1426-1445) and of the shortcut vote (:767-789),
+  // the same as in bn_kernel.hip; `store` decides whether the normalised values are written
+  auto single_pass = [&](bool flags_pass, bool store) {
+    for (int p = 0; p < N; ++p) {
+      const int fk = m.gender[p] == 1 ? 0 : 1;
+      s << "    { const double a0 = l" << p << "_0, a1 = l" << p << "_1, a2 = l" << p << "_2;\n"
+        << "      const double p0 = a0 * tcf[" << fk * 27 << "], p1 = a1 * tcf[" << fk * 27 + 9 << "], p2 = a2 * tcf["
+        << fk * 27 + 18 << "];\n      const double s = (p0 + p1) + p2;";
+      if (flags_pass) s << " if (s <= 0) single_fail = true;";
+      s << "\n";
+      if (store)
+        s << "      row[" << 3 * p << "] = p0 / s; row[" << 3 * p + 1 << "] = p1 / s; row[" << 3 * p + 2 << "] = p2 / s;\n";
+      if (flags_pass && m.sequenced[p])
+        s << "      double big = 0; if (big < a0) big = a0; if (big < a1) big = a1; if (big < a2) big = a2;\n"
+          << "      const double sum = (a0 + a1) + a2; big = big / sum; if (big < lc) full = true;\n";
+      s << "    }\n";
+    }
+  };
+  if (regs_l) {
+    for (int p = 0; p < N; ++p)
+      for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = row[" << 3 * p + gt << "];\n";
+    s << "    LDS_BARRIER();  // every lane holds its row in registers: the rows become the output stage\n";
+    single_pass(true, true);
+    s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
+      << "    LDS_BARRIER();\n"
+      << "    if (single_g) { STAGE(single_g[site0 * W3 + e] = s_io[a]); }\n"
+      << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n"
+      << "    if (full && !single_fail) {\n"
+      << body
+      << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
+      << "    }\n"
+      << "    LDS_BARRIER();\n"
+      << "    STAGE(post_g[site0 * W3 + e] = s_io[a]);\n"
+      << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
+      << "  }\n}\n";
+  } else {
+    // Outputs are staged through the same LDS rows as the input (coalesced 8 B/lane stores).
+    // Writing each lane's row straight from registers was measured 20 % slower on MI355X
+    // (64 partial-line requests per store instruction), so the extra barriers stay.
+    single_pass(true, false);
+    s << "    double q[W3];\n"
+      << "    if (full && !single_fail) {\n"
+      << body << "    }\n";
+    single_pass(false, true);  // now the single posterior may take the row over
+    s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
+      << "    LDS_BARRIER();\n"
+      << "    if (single_g) { STAGE(single_g[site0 * W3 + e] = s_io[a]); }\n"
+      << "    LDS_BARRIER();  // single rows are stored; sites that ran the full computation overwrite theirs\n"
+      << "    if (full && !single_fail) {\n"
+      << "#pragma unroll\n      for (int k = 0; k < W3; ++k) row[k] = bn_fail ? kNaN : q[k];\n"
+      << "    }\n"
+      << "    LDS_BARRIER();\n"
+      << "    STAGE(post_g[site0 * W3 + e] = s_io[a]);\n"
+      << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
+      << "  }\n}\n";
   }
-  s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
-    << "    __syncthreads();\n"
-    << "    if (single_g) for (int e = tid; e < nel; e += BT) { const int si = e / W3; single_g[site0 * W3 + e] = s_io[si * ROW + (e - si * W3)]; }\n"
-    << "    __syncthreads();  // single rows are stored; sites that need the full computation overwrite theirs\n"
-    << "    if (full && !single_fail) {\n"
-    << body
-    << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
-    << "    }\n"
-    << "    __syncthreads();\n"
-    << "    for (int e = tid; e < nel; e += BT) { const int si = e / W3; post_g[site0 * W3 + e] = s_io[si * ROW + (e - si * W3)]; }\n"
-    << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
-    << "  }\n}\n";
   return s.str();
 }
 
@@ -302,7 +359,7 @@ std::string elim_source(const famseq_model &m) {
   const int bt = elim_block_threads(m);
   return kernel_shell(m, "famseq_elim",
                       "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families", Emitter(m, g).body(),
-                      bt, bt / 128);
+                      bt, bt / 128, /*regs_l=*/false);
 }
 
 }  // namespace famseq

@@ -263,7 +263,7 @@ std::string enumgen_source(const famseq_model &m) {
   const int bt = enumgen_block_threads(m);
   std::string what = "3^N enumeration, lane per site, " + std::to_string(s.outer.size()) + " looped + " +
                      std::to_string(s.unrolled.size()) + " unrolled members";
-  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s).body(), bt, bt / 128);
+  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s).body(), bt, bt / 128, /*regs_l=*/true);
 }
 
 }  // namespace famseq

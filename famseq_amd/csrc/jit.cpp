@@ -86,7 +86,11 @@ std::string jit_compile(const std::string &source) {
     throw std::runtime_error("kernel compilation failed (" + cmd + "): " + log.substr(0, 2000));
   }
   ::rename(tmp.c_str(), obj.c_str());  // atomic publish: concurrent ranks may compile the same kernel
-  ::unlink(src.c_str());
+  if (std::getenv("FAMSEQ_KEEP_SRC")) {  // debugging aid: keep the generated source next to the object
+    ::rename(src.c_str(), (dir + "/" + name + ".hip").c_str());
+  } else {
+    ::unlink(src.c_str());
+  }
   ::unlink((src + ".log").c_str());
   return obj;
 }
