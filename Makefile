@@ -7,7 +7,7 @@ CSRC := famseq_amd/csrc
 LIB := famseq_amd/lib/libfamseq_hip.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-result
 
-SRCS := $(CSRC)/bn_kernel.hip $(CSRC)/capi.cpp $(CSRC)/plan.cpp $(CSRC)/model.cpp $(CSRC)/jit.cpp $(CSRC)/elim_codegen.cpp $(CSRC)/enum_codegen.cpp
+SRCS := $(CSRC)/bn_kernel.hip $(CSRC)/io_kernels.hip $(CSRC)/capi.cpp $(CSRC)/plan.cpp $(CSRC)/model.cpp $(CSRC)/jit.cpp $(CSRC)/elim_codegen.cpp $(CSRC)/enum_codegen.cpp
 OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 
 CLI := bin/FamSeq

@@ -56,8 +56,9 @@ class CModel(C.Structure):
 ABI_SYMBOLS = [
     "famseq_transmission_tables", "famseq_model_init", "famseq_device_count", "famseq_create",
     "famseq_destroy", "famseq_last_error", "famseq_set_option", "famseq_plan_json",
-    "famseq_bn_batch", "famseq_bn_batch_device", "famseq_call_genotypes",
+    "famseq_bn_batch", "famseq_bn_batch_device", "famseq_bn_call_batch", "famseq_call_genotypes",
 ]
+PL_MISSING = 0xFFFF
 
 _lib = None
 
@@ -101,6 +102,9 @@ def lib():
     vp = C.c_void_p
     L.famseq_bn_batch_device.argtypes = [C.c_void_p, C.c_int64, vp, vp, vp, vp, vp, vp]
     L.famseq_bn_batch_device.restype = C.c_int
+    L.famseq_bn_call_batch.argtypes = [C.c_void_p, C.c_int64, dp, C.POINTER(C.c_uint16), bp, ip, C.c_int32, dp, dp,
+                                       C.POINTER(C.c_int8), bp]
+    L.famseq_bn_call_batch.restype = C.c_int
     L.famseq_call_genotypes.argtypes = [dp, C.c_int64, C.POINTER(C.c_int8)]
     L.famseq_call_genotypes.restype = None
     _lib = L
@@ -160,7 +164,11 @@ class Context:
             lib().famseq_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def _check(self, rc, what):
         if rc != 0:
@@ -187,6 +195,29 @@ class Context:
                                    None if status is None else _p(status, C.c_uint8))
         self._check(rc, "famseq_bn_batch")
         return post, single, status
+
+    def bn_call_batch(self, seq_members, lk=None, pl16=None, flags=None):
+        """Fused call path: -> (gpp[S,n_seq,3], fpp[S,n_seq,3], fgt[S,n_seq], status[S]).
+        Input is either lk [S,N,3] float64 or pl16 [S,n_seq,3] uint16 (VCF column order)."""
+        seq = np.ascontiguousarray(seq_members, dtype=np.int32)
+        k = len(seq)
+        if (lk is None) == (pl16 is None):
+            raise ValueError("give exactly one of lk / pl16")
+        if lk is not None:
+            lk = np.ascontiguousarray(lk, dtype=np.float64).reshape(-1, self.n, 3)
+            s = lk.shape[0]
+        else:
+            pl16 = np.ascontiguousarray(pl16, dtype=np.uint16).reshape(-1, k, 3)
+            s = pl16.shape[0]
+        fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
+        gpp, fpp = np.empty((s, k, 3)), np.empty((s, k, 3))
+        fgt, status = np.empty((s, k), np.int8), np.zeros(s, np.uint8)
+        rc = lib().famseq_bn_call_batch(self._h, s, None if lk is None else _p(lk, C.c_double),
+                                        None if pl16 is None else _p(pl16, C.c_uint16),
+                                        None if fl is None else _p(fl, C.c_uint8), _p(seq, C.c_int32), k,
+                                        _p(gpp, C.c_double), _p(fpp, C.c_double), _p(fgt, C.c_int8), _p(status, C.c_uint8))
+        self._check(rc, "famseq_bn_call_batch")
+        return gpp, fpp, fgt, status
 
     def bn_batch_device(self, n_sites, d_lk, d_flags, d_post, d_single=0, d_status=0, stream=0):
         """Raw device pointers (ints); enqueues on `stream` and returns."""

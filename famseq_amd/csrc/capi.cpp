@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -19,6 +20,7 @@
 #include "enum_codegen.h"
 #include "jit.h"
 #include "famseq_hip.h"
+#include "io_kernels.h"
 #include "plan.h"
 
 using namespace famseq;
@@ -54,6 +56,14 @@ struct famseq_ctx {
   int64_t slot_sites = 0;
   double *d_lk[kSlots] = {}, *d_post[kSlots] = {}, *d_single[kSlots] = {};
   uint8_t *d_flags[kSlots] = {}, *d_status[kSlots] = {};
+  // packed input / called output stages (famseq_bn_call_batch*)
+  int slot_seq = 0;
+  uint16_t *d_pl[kSlots] = {};
+  double *d_gpp[kSlots] = {}, *d_fpp[kSlots] = {};
+  int8_t *d_fgt[kSlots] = {};
+  double *d_lut = nullptr;
+  int32_t *d_seq = nullptr, *d_col = nullptr;
+  std::vector<int32_t> seq_members;
   std::string err, json;
 };
 
@@ -94,10 +104,18 @@ void free_slots(famseq_ctx *c) {
     if (c->d_single[s]) (void)hipFree(c->d_single[s]);
     if (c->d_flags[s]) (void)hipFree(c->d_flags[s]);
     if (c->d_status[s]) (void)hipFree(c->d_status[s]);
+    if (c->d_pl[s]) (void)hipFree(c->d_pl[s]);
+    if (c->d_gpp[s]) (void)hipFree(c->d_gpp[s]);
+    if (c->d_fpp[s]) (void)hipFree(c->d_fpp[s]);
+    if (c->d_fgt[s]) (void)hipFree(c->d_fgt[s]);
     c->d_lk[s] = c->d_post[s] = c->d_single[s] = nullptr;
     c->d_flags[s] = c->d_status[s] = nullptr;
+    c->d_pl[s] = nullptr;
+    c->d_gpp[s] = c->d_fpp[s] = nullptr;
+    c->d_fgt[s] = nullptr;
   }
   c->slot_sites = 0;
+  c->slot_seq = 0;
 }
 
 // (Re)build the plan and, on a device ctx, upload its image and the factor tables.
@@ -280,6 +298,9 @@ extern "C" void famseq_destroy(famseq_ctx *c) {
     if (c->d_tc) (void)hipFree(c->d_tc);
     jit_unload(c->elim);
     jit_unload(c->lane);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_seq) (void)hipFree(c->d_seq);
+    if (c->d_col) (void)hipFree(c->d_col);
     for (int s = 0; s < famseq_ctx::kSlots; ++s)
       if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
   }
@@ -349,26 +370,73 @@ extern "C" int famseq_bn_batch_device(famseq_ctx *c, int64_t n_sites, const doub
   return 0;
 }
 
-extern "C" int famseq_bn_batch(famseq_ctx *c, int64_t n_sites, const double *lk, const uint8_t *flags, double *post,
-                               double *post_single, uint8_t *status) {
-  if (!c) return FAMSEQ_E_ARG;
+namespace {
+
+struct HostIO {
+  const double *lk = nullptr;      // exactly one of lk / pl16
+  const uint16_t *pl16 = nullptr;  // [n_sites][n_seq][3]
+  const uint8_t *flags = nullptr;
+  double *post = nullptr, *single = nullptr;  // raw outputs [n_sites][N][3]
+  uint8_t *status = nullptr;
+  double *gpp = nullptr, *fpp = nullptr;  // called outputs [n_sites][n_seq][3]
+  int8_t *fgt = nullptr;                  // [n_sites][n_seq]
+};
+
+// Upload the sequenced-member list (VCF column order) and its inverse when it changes.
+int set_sequenced(famseq_ctx *c, const int32_t *seq, int n_seq) {
+  if (n_seq < 0 || n_seq > c->plan.N || (n_seq > 0 && !seq)) return fail(c, FAMSEQ_E_ARG, "bad sequenced-member list");
+  std::vector<int32_t> v(seq, seq + n_seq), col(c->plan.N, -1);
+  for (int k = 0; k < n_seq; ++k) {
+    if (v[k] < 0 || v[k] >= c->plan.N || col[v[k]] >= 0) return fail(c, FAMSEQ_E_ARG, "bad sequenced-member list");
+    col[v[k]] = k;
+  }
+  if (c->d_seq && v == c->seq_members) return 0;
+  if (!c->d_seq) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_seq), FAMSEQ_MAX_MEMBERS * sizeof(int32_t)));
+  if (!c->d_col) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_col), FAMSEQ_MAX_MEMBERS * sizeof(int32_t)));
+  if (n_seq) HIP_TRY(c, hipMemcpy(c->d_seq, v.data(), n_seq * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_col, col.data(), col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  c->seq_members = v;
+  return 0;
+}
+
+// Chunked host pipeline shared by every host-buffer entry point: per chunk, on one of two
+// streams, H2D -> [unpack] -> posterior kernel -> [phred/call] -> D2H; the two streams overlap
+// the copies of one chunk with the compute of the other.
+int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
   if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
-  if (n_sites < 0 || (n_sites > 0 && (!lk || !post))) return fail(c, FAMSEQ_E_ARG, "bad batch arguments");
   if (n_sites == 0) return 0;
   HIP_TRY(c, hipSetDevice(c->device));
-  const size_t row = size_t(3) * c->plan.N * sizeof(double);
+  const int N = c->plan.N;
+  const size_t row = size_t(3) * N * sizeof(double);
+  const bool called = io.gpp || io.fpp || io.fgt;
   int64_t chunk = c->chunk_sites > 0 ? c->chunk_sites : std::max<int64_t>(1, (int64_t(64) << 20) / int64_t(row));
   chunk = std::min(chunk, n_sites);
-  if (c->slot_sites < chunk) {
+  const int want_seq = (io.pl16 || called) ? std::max(n_seq, 1) : 0;
+  if (c->slot_sites < chunk || c->slot_seq < want_seq) {
+    const int64_t cap = std::max(chunk, c->slot_sites);
+    const int seqcap = std::max(want_seq, c->slot_seq);
     free_slots(c);
     for (int s = 0; s < famseq_ctx::kSlots; ++s) {
-      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_lk[s]), chunk * row));
-      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_post[s]), chunk * row));
-      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_single[s]), chunk * row));
-      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_flags[s]), chunk));
-      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_status[s]), chunk));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_lk[s]), cap * row));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_post[s]), cap * row));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_single[s]), cap * row));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_flags[s]), cap));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_status[s]), cap));
+      if (seqcap) {
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_pl[s]), cap * seqcap * 3 * sizeof(uint16_t)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_gpp[s]), cap * seqcap * 3 * sizeof(double)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_fpp[s]), cap * seqcap * 3 * sizeof(double)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_fgt[s]), cap * seqcap));
+      }
     }
-    c->slot_sites = chunk;
+    c->slot_sites = cap;
+    c->slot_seq = seqcap;
+  }
+  if (io.pl16 && !c->d_lut) {  // pow(10,-k/10) through the host's libm, as file.cpp:589 computes it
+    std::vector<double> lut(kPlLutSize);
+    for (int k = 0; k < kPlLutSize; ++k) lut[k] = std::pow(10.0, -std::fabs(double(k)) / 10.0);
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_lut), lut.size() * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   int k = 0;
   for (int64_t lo = 0; lo < n_sites; lo += chunk, ++k) {
@@ -376,15 +444,57 @@ extern "C" int famseq_bn_batch(famseq_ctx *c, int64_t n_sites, const double *lk,
     const int64_t n = std::min(chunk, n_sites - lo);
     hipStream_t st = c->stream[s];
     HIP_TRY(c, hipStreamSynchronize(st));  // the slot's previous chunk has fully drained
-    HIP_TRY(c, hipMemcpyAsync(c->d_lk[s], lk + lo * 3 * c->plan.N, n * row, hipMemcpyHostToDevice, st));
-    if (flags) HIP_TRY(c, hipMemcpyAsync(c->d_flags[s], flags + lo, n, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, launch_engine(c, n, c->d_lk[s], flags ? c->d_flags[s] : nullptr, c->d_post[s],
-                             post_single ? c->d_single[s] : nullptr, status ? c->d_status[s] : nullptr, st));
-    HIP_TRY(c, hipMemcpyAsync(post + lo * 3 * c->plan.N, c->d_post[s], n * row, hipMemcpyDeviceToHost, st));
-    if (post_single)
-      HIP_TRY(c, hipMemcpyAsync(post_single + lo * 3 * c->plan.N, c->d_single[s], n * row, hipMemcpyDeviceToHost, st));
-    if (status) HIP_TRY(c, hipMemcpyAsync(status + lo, c->d_status[s], n, hipMemcpyDeviceToHost, st));
+    if (io.pl16) {
+      HIP_TRY(c, hipMemcpyAsync(c->d_pl[s], io.pl16 + lo * n_seq * 3, n * n_seq * 3 * sizeof(uint16_t),
+                                hipMemcpyHostToDevice, st));
+      HIP_TRY(c, launch_unpack_pl16(c->d_pl[s], c->d_col, c->d_lut, N, n_seq, n, c->d_lk[s], st));
+    } else {
+      HIP_TRY(c, hipMemcpyAsync(c->d_lk[s], io.lk + lo * 3 * N, n * row, hipMemcpyHostToDevice, st));
+    }
+    if (io.flags) HIP_TRY(c, hipMemcpyAsync(c->d_flags[s], io.flags + lo, n, hipMemcpyHostToDevice, st));
+    const bool need_single = io.single || io.gpp;
+    const bool need_status = io.status || called;
+    HIP_TRY(c, launch_engine(c, n, c->d_lk[s], io.flags ? c->d_flags[s] : nullptr, c->d_post[s],
+                             need_single ? c->d_single[s] : nullptr, need_status ? c->d_status[s] : nullptr, st));
+    if (called) {
+      HIP_TRY(c, launch_phred_call(c->d_post[s], c->d_single[s], c->d_status[s], c->d_seq, N, n_seq, n, c->d_gpp[s],
+                                   c->d_fpp[s], c->d_fgt[s], st));
+      const size_t cr = size_t(3) * n_seq * sizeof(double);
+      if (io.gpp) HIP_TRY(c, hipMemcpyAsync(io.gpp + lo * 3 * n_seq, c->d_gpp[s], n * cr, hipMemcpyDeviceToHost, st));
+      if (io.fpp) HIP_TRY(c, hipMemcpyAsync(io.fpp + lo * 3 * n_seq, c->d_fpp[s], n * cr, hipMemcpyDeviceToHost, st));
+      if (io.fgt) HIP_TRY(c, hipMemcpyAsync(io.fgt + lo * n_seq, c->d_fgt[s], n * n_seq, hipMemcpyDeviceToHost, st));
+    }
+    if (io.post) HIP_TRY(c, hipMemcpyAsync(io.post + lo * 3 * N, c->d_post[s], n * row, hipMemcpyDeviceToHost, st));
+    if (io.single) HIP_TRY(c, hipMemcpyAsync(io.single + lo * 3 * N, c->d_single[s], n * row, hipMemcpyDeviceToHost, st));
+    if (io.status) HIP_TRY(c, hipMemcpyAsync(io.status + lo, c->d_status[s], n, hipMemcpyDeviceToHost, st));
   }
   for (int s = 0; s < famseq_ctx::kSlots; ++s) HIP_TRY(c, hipStreamSynchronize(c->stream[s]));
   return 0;
+}
+
+}  // namespace
+
+extern "C" int famseq_bn_batch(famseq_ctx *c, int64_t n_sites, const double *lk, const uint8_t *flags, double *post,
+                               double *post_single, uint8_t *status) {
+  if (!c) return FAMSEQ_E_ARG;
+  if (n_sites < 0 || (n_sites > 0 && (!lk || !post))) return fail(c, FAMSEQ_E_ARG, "bad batch arguments");
+  HostIO io;
+  io.lk = lk; io.flags = flags; io.post = post; io.single = post_single; io.status = status;
+  return run_host(c, n_sites, io, 0);
+}
+
+extern "C" int famseq_bn_call_batch(famseq_ctx *c, int64_t n_sites, const double *lk, const uint16_t *pl16,
+                                    const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, double *gpp,
+                                    double *fpp, int8_t *fgt, uint8_t *status) {
+  if (!c) return FAMSEQ_E_ARG;
+  if (n_sites < 0 || (n_sites > 0 && ((lk == nullptr) == (pl16 == nullptr))))
+    return fail(c, FAMSEQ_E_ARG, "exactly one of lk / pl16 must be given");
+  if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
+  if (n_seq < 1) return fail(c, FAMSEQ_E_ARG, "n_seq must be >= 1");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int rc = set_sequenced(c, seq_members, n_seq);
+  if (rc != 0) return rc;
+  HostIO io;
+  io.lk = lk; io.pl16 = pl16; io.flags = flags; io.gpp = gpp; io.fpp = fpp; io.fgt = fgt; io.status = status;
+  return run_host(c, n_sites, io, n_seq);
 }

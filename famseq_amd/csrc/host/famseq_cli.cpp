@@ -24,7 +24,6 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
-#include <limits>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -58,13 +57,6 @@ void put_double(string &out, double v) {
   out += buf;
 }
 
-// fabs(-10*log10(p)), +inf -> 99999  (file.cpp:696-703)
-void put_phred(string &out, double p) {
-  const double q = -10 * std::log10(p);
-  if (q == std::numeric_limits<double>::infinity()) out += "99999";
-  else put_double(out, std::fabs(q));
-}
-
 // pow(10, -|x|/10) for a PL/GL field (file.cpp:588-590).  Integer fields (the usual PL) go
 // through a table filled with the same libm pow call, so the value is identical.
 struct PlTable {
@@ -72,11 +64,17 @@ struct PlTable {
   PlTable() : lut(4096) {
     for (size_t k = 0; k < lut.size(); ++k) lut[k] = std::pow(10.0, -std::fabs(double(k)) / 10.0);
   }
-  double operator()(const char *b, const char *e) const {
-    unsigned v = 0;
+  // *packed receives the integer PL (clamped to 65534: anything >= 3240 is exactly 0 anyway) or
+  // is left untouched and *integral cleared when the field is not a plain non-negative integer.
+  double operator()(const char *b, const char *e, uint16_t *packed, bool *integral) const {
+    unsigned long v = 0;
     const char *p = b;
-    while (p < e && *p >= '0' && *p <= '9' && v < 100000) v = v * 10 + unsigned(*p++ - '0');
-    if (p == e && p > b && v < lut.size()) return lut[v];
+    while (p < e && *p >= '0' && *p <= '9' && v < 100000000ul) v = v * 10 + unsigned(*p++ - '0');
+    if (p == e && p > b) {
+      *packed = uint16_t(v < 65534 ? v : 65534);
+      return v < lut.size() ? lut[v] : std::pow(10.0, -std::fabs(double(v)) / 10.0);
+    }
+    *integral = false;
     const double x = std::atof(string(b, e).c_str());
     return std::pow(10.0, -std::fabs(x) / 10.0);
   }
@@ -315,57 +313,62 @@ struct Record {
 class BatchCaller {
  public:
   BatchCaller(famseq_ctx *ctx, int n_members, const vector<int> &seq_members, std::ostream &out, size_t cap)
-      : ctx_(ctx), n_(n_members), seq_(seq_members), out_(out), cap_(cap) {}
+      : ctx_(ctx), n_(n_members), seq_(seq_members.begin(), seq_members.end()), out_(out), cap_(cap) {}
 
   void literal(string line) {
     Record r;
     r.text = std::move(line);
     q_.push_back(std::move(r));
   }
-  // lk: N x 3 in PED order
-  bool site(Record &&r, const vector<double> &lk, uint8_t flags) {
+  // lk: N x 3 in PED order; pl: n_seq x 3 packed integer PLs in column order, or NULL when some
+  // field of the site is not a plain integer (the batch then goes through the fp64 input)
+  bool site(Record &&r, const vector<double> &lk, const uint16_t *pl, uint8_t flags) {
     r.site = (long)flags_.size();
     lk_.insert(lk_.end(), lk.begin(), lk.end());
+    if (pl && packed_ok_) pl_.insert(pl_.end(), pl, pl + 3 * seq_.size());
+    else packed_ok_ = false;
     flags_.push_back(flags);
     q_.push_back(std::move(r));
     return flags_.size() < cap_ || flush();
   }
+  // Posterior, Phred scaling and genotype call all happen on the device (famseq_bn_call_batch);
+  // what comes back per sequenced sample is exactly what gets printed.
   bool flush() {
     const int64_t s = (int64_t)flags_.size();
-    post_.resize(lk_.size());
-    single_.resize(lk_.size());
+    const size_t k = seq_.size();
+    gpp_.resize(size_t(s) * k * 3);
+    fpp_.resize(size_t(s) * k * 3);
+    fgt_.resize(size_t(s) * k);
     status_.resize(flags_.size());
     if (s > 0) {
-      const int rc = famseq_bn_batch(ctx_, s, lk_.data(), flags_.data(), post_.data(), single_.data(), status_.data());
+      const bool packed = packed_ok_ && !pl_.empty();
+      const int rc = famseq_bn_call_batch(ctx_, s, packed ? nullptr : lk_.data(), packed ? pl_.data() : nullptr,
+                                          flags_.data(), seq_.data(), (int32_t)k, gpp_.data(), fpp_.data(), fgt_.data(),
+                                          status_.data());
       if (rc != 0) {
-        std::cerr << "famseq_bn_batch failed (" << rc << "): " << famseq_last_error(ctx_) << std::endl;
+        std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx_) << std::endl;
         return false;
       }
     }
     string line;
-    vector<int8_t> gt(seq_.size());
-    vector<double> rows(3 * seq_.size());
     for (Record &r : q_) {
       line.assign(r.text);
       if (r.site >= 0) {
-        const size_t base = size_t(r.site) * 3 * n_;
         if (status_[r.site] & 3) {  // file.cpp:607-620
           std::cout << "Warning: this variant hasn't been calculated: " << std::endl << r.raw << std::endl;
           for (const string &f : r.fail_fields) line += f + ":NA:NA:NA\t";
         } else {
-          for (size_t k = 0; k < seq_.size(); ++k)
-            for (int g = 0; g < 3; ++g) rows[3 * k + g] = post_[base + 3 * seq_[k] + g];
-          famseq_call_genotypes(rows.data(), (int64_t)seq_.size(), gt.data());
-          for (size_t k = 0; k < seq_.size(); ++k) {
-            const double *sp = &single_[base + 3 * seq_[k]], *pp = &rows[3 * k];
-            line += r.fields[k];
-            put_phred(line, sp[0]); line += ',';
-            put_phred(line, sp[1]); line += ',';
-            put_phred(line, sp[2]); line += ':';
-            put_phred(line, pp[0]); line += ',';
-            put_phred(line, pp[1]); line += ',';
-            put_phred(line, pp[2]); line += ':';
-            line += gt[k] == 0 ? "0/0\t" : (gt[k] == 1 ? "0/1\t" : "1/1\t");
+          for (size_t j = 0; j < k; ++j) {
+            const double *g = &gpp_[(size_t(r.site) * k + j) * 3], *f = &fpp_[(size_t(r.site) * k + j) * 3];
+            const int gt = fgt_[size_t(r.site) * k + j];
+            line += r.fields[j];
+            put_double(line, g[0]); line += ',';
+            put_double(line, g[1]); line += ',';
+            put_double(line, g[2]); line += ':';
+            put_double(line, f[0]); line += ',';
+            put_double(line, f[1]); line += ',';
+            put_double(line, f[2]); line += ':';
+            line += gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t");
           }
         }
       }
@@ -373,19 +376,24 @@ class BatchCaller {
     }
     q_.clear();
     lk_.clear();
+    pl_.clear();
     flags_.clear();
+    packed_ok_ = true;
     return true;
   }
 
  private:
   famseq_ctx *ctx_;
   int n_;
-  vector<int> seq_;  // PED index of each sequenced output column, in input column order
+  vector<int32_t> seq_;  // PED index of each sequenced output column, in input column order
   std::ostream &out_;
   size_t cap_;
   vector<Record> q_;
-  vector<double> lk_, post_, single_;
+  vector<double> lk_, gpp_, fpp_;
+  vector<uint16_t> pl_;
+  vector<int8_t> fgt_;
   vector<uint8_t> flags_, status_;
+  bool packed_ok_ = true;
 };
 
 size_t batch_capacity() {
@@ -545,6 +553,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
   const PlTable pl;
   const size_t n_seq = seq_cols.size();
   vector<double> lk(size_t(3) * ped.n());
+  vector<uint16_t> pl16(3 * n_seq);
   bool ok = true;
 
   auto echo = [&](const vector<string> &t) {  // the "allLine" echo: 9 columns + sequenced samples
@@ -601,7 +610,11 @@ bool run_vcf(const Options &o, const Ped &ped) {
     r.text += t[8] + ":GPP:FPP:FGT\t";
     r.raw = line;
     std::fill(lk.begin(), lk.end(), 1.0);
+    std::fill(pl16.begin(), pl16.end(), uint16_t(0xFFFF));  // 0xFFFF x3 = missing sample
+    bool integral = true;
+    size_t col = 0;
     for (int c : seq_cols) {
+      const size_t this_col = col++;
       const string &f = t[9 + c];
       r.fail_fields.push_back(f);
       if (f.size() < 5) {  // missing sample: flat likelihood, printed as NA per FORMAT key (file.cpp:927-933)
@@ -618,11 +631,11 @@ bool run_vcf(const Options &o, const Ped &ped) {
       for (int g = 0; g < 3; g++) {
         const char *e = static_cast<const char *>(std::memchr(b, ',', size_t(end - b)));
         if (!e) e = end;
-        lk[size_t(3) * v2p[c] + g] = pl(b, e);
+        lk[size_t(3) * v2p[c] + g] = pl(b, e, &pl16[3 * this_col + g], &integral);
         b = e < end ? e + 1 : end;
       }
     }
-    ok = caller.site(std::move(r), lk, flags);
+    ok = caller.site(std::move(r), lk, integral ? pl16.data() : nullptr, flags);
   }
   ok = ok && caller.flush();
   famseq_destroy(ctx);
@@ -692,7 +705,7 @@ bool run_lk(const Options &o, const Ped &ped) {
         lk[size_t(3) * v2p[c] + g] = x;
       }
     }
-    ok = caller.site(std::move(r), lk, 0);  // calPostProbBN() defaults: Known=false, chrType=0 (file.cpp:1751)
+    ok = caller.site(std::move(r), lk, nullptr, 0);  // calPostProbBN() defaults: Known=false, chrType=0 (file.cpp:1751)
   }
   ok = ok && caller.flush();
   famseq_destroy(ctx);

@@ -135,6 +135,22 @@ int famseq_bn_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, const ui
 int famseq_bn_batch_device(famseq_ctx *ctx, int64_t n_sites, const double *d_lk, const uint8_t *d_flags,
                            double *d_post, double *d_post_single, uint8_t *d_status, void *stream);
 
+/* Fused call path (SURVEY.md 8(f) rows N2 + N4): what the drivers print per sequenced sample, computed on
+ * the device, so that only 49*n_seq bytes per site come back instead of 48*N.
+ *   input   either lk  [n_sites][N][3] fp64 (as famseq_bn_batch)
+ *           or     pl16 [n_sites][n_seq][3] uint16: integer PL/GL magnitudes in VCF column order, turned
+ *                  into likelihoods on the device with the reference's pow(10,-|x|/10) (file.cpp:588-590,
+ *                  table filled by the host libm); 0xFFFF,0xFFFF,0xFFFF = sample missing at this site
+ *                  (likelihood {1,1,1}, file.cpp:794-809); members outside seq_members are {1,1,1} (:565)
+ *   seq_members[n_seq]  PED index of each sequenced sample in VCF column order (mapV2P[i] >= 0)
+ *   gpp, fpp [n_sites][n_seq][3]  fabs(-10*log10(p)) of the single / BN posterior, +inf -> 99999
+ *                                 (file.cpp:696-745); NaN where the site failed
+ *   fgt      [n_sites][n_seq]     arg-max genotype 0/1/2 (family.cpp:636-665), -1 where the site failed
+ * Any of gpp / fpp / fgt / status may be NULL.  Blocking; chunks are pipelined like famseq_bn_batch. */
+int famseq_bn_call_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, const uint16_t *pl16,
+                         const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, double *gpp, double *fpp,
+                         int8_t *fgt, uint8_t *status);
+
 /* get_postRlt (family.cpp:636-665) for one N x 3 posterior row block: arg-max with
  * strict '<' starting from -1, so ties resolve to the lowest genotype. */
 void famseq_call_genotypes(const double *post, int64_t n_rows, int8_t *geno);
