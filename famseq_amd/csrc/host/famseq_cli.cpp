@@ -84,6 +84,9 @@ struct PlTable {
 
 struct Options {
   bool lk_mode = false;
+  bool pack_mode = false;  // `FamSeq pack`: vcf -> packed binary PL file (no GPU)
+  bool pl_mode = false;    // `FamSeq PL`: packed binary PL file -> calls
+  string pl_file;
   vector<string> vcf_files;
   string lk_file, ped_file, out_file, loc_file;
   bool var_only = false, all_line = false, diff_only = false, pos_order = false;
@@ -142,6 +145,8 @@ int parse_options(int argc, char **argv, Options &o) {
         }
         o.vcf_files.push_back(argv[i]);
       }
+    } else if (o.pl_mode && opt == "plFile") {
+      if (!need_file(o.pl_file, "packed PL file")) return -1;
     } else if (o.lk_mode && opt == "lkFile") {
       if (!need_file(o.lk_file, "likelihood file")) return -1;
     } else if (opt == "pedFile") {
@@ -230,7 +235,11 @@ int parse_options(int argc, char **argv, Options &o) {
     std::cout << "The name of vcf file must be set. Please input the vcf file name." << std::endl;
     return -1;
   }
-  if (o.lk_mode && o.lk_file.empty()) {
+  if (o.pl_mode && o.pl_file.empty()) {
+    std::cout << "The name of packed PL file must be set. Please input the file name (-plFile)." << std::endl;
+    return -1;
+  }
+  if (o.lk_mode && !o.pl_mode && o.lk_file.empty()) {
     std::cout << "The name of likelihood file must be set. Please input the likelihood file name." << std::endl;
     return -1;
   }
@@ -429,6 +438,164 @@ famseq_ctx *make_ctx(const Options &o, const Ped &ped, const vector<uint8_t> &se
 
 void put_triple(std::ostream &o, const double *p) { o << p[0] << ":" << p[1] << ":" << p[2]; }
 
+// ---- packed PL file (row N4 of SURVEY.md 8(f)): the text-free feed for the GPU ---------------
+//   bytes 0-7   "FSPL0001"
+//   8-11        uint32 n_seq            sequenced samples (columns)
+//   12-15       uint32 record_bytes     = 1 + 6*n_seq
+//   16-23       uint64 n_sites          (0 while being written; patched on close)
+//   24-...      n_seq x char[32]        sample names, NUL padded
+//   then n_sites records: uint8 flags (bit0 Known, bit1 chrX); uint16 pl[n_seq][3] little endian,
+//   integer PL clamped to 65534, 0xFFFF x3 = sample missing at the site.
+// Only sites the vcf driver would compute are written (same site rules, file.cpp:362-555).
+const char kPlMagic[9] = "FSPL0001";
+
+struct PackWriter {
+  std::ofstream out;
+  uint32_t n_seq = 0;
+  uint64_t n_sites = 0, skipped = 0;
+  bool open(const string &path, const vector<string> &names) {
+    out.open(path.c_str(), std::ios::binary);
+    if (!out.is_open()) return false;
+    n_seq = (uint32_t)names.size();
+    const uint32_t rec = 1 + 6 * n_seq;
+    const uint64_t zero = 0;
+    out.write(kPlMagic, 8);
+    out.write(reinterpret_cast<const char *>(&n_seq), 4);
+    out.write(reinterpret_cast<const char *>(&rec), 4);
+    out.write(reinterpret_cast<const char *>(&zero), 8);
+    for (const string &n : names) {
+      char buf[32] = {0};
+      std::strncpy(buf, n.c_str(), 31);
+      out.write(buf, 32);
+    }
+    return bool(out);
+  }
+  void add(uint8_t flags, const uint16_t *pl) {
+    out.write(reinterpret_cast<const char *>(&flags), 1);
+    out.write(reinterpret_cast<const char *>(pl), 6 * n_seq);
+    ++n_sites;
+  }
+  bool close() {
+    out.seekp(16);
+    out.write(reinterpret_cast<const char *>(&n_sites), 8);
+    out.close();
+    return !out.fail();
+  }
+};
+
+bool run_pl(const Options &o, const Ped &ped) {
+  std::ifstream fin(o.pl_file.c_str(), std::ios::binary);
+  if (!fin.is_open()) {
+    std::cout << "Cannot open " << o.pl_file << std::endl;
+    return false;
+  }
+  char magic[8];
+  uint32_t n_seq = 0, rec = 0;
+  uint64_t n_sites = 0;
+  fin.read(magic, 8);
+  fin.read(reinterpret_cast<char *>(&n_seq), 4);
+  fin.read(reinterpret_cast<char *>(&rec), 4);
+  fin.read(reinterpret_cast<char *>(&n_sites), 8);
+  if (!fin || std::memcmp(magic, kPlMagic, 8) != 0 || n_seq == 0 || n_seq > 4096 || rec != 1 + 6 * n_seq) {
+    std::cout << o.pl_file << " is not a packed PL file." << std::endl;
+    return false;
+  }
+  vector<string> names(n_seq);
+  for (uint32_t i = 0; i < n_seq; i++) {
+    char buf[33] = {0};
+    fin.read(buf, 32);
+    names[i] = buf;
+  }
+  // columns -> PED members (file.cpp:1671-1689); columns that are not in the PED are ignored
+  vector<int> col_member(n_seq, -1);
+  vector<uint8_t> sequenced(ped.n(), 0);
+  for (uint32_t i = 0; i < n_seq; i++)
+    for (int j = 0; j < ped.n(); j++)
+      if (names[i] == ped.name[j]) {
+        col_member[i] = j;
+        sequenced[j] = 1;
+        break;
+      }
+  vector<int32_t> seq_members;
+  vector<uint32_t> seq_cols;
+  for (uint32_t i = 0; i < n_seq; i++)
+    if (col_member[i] >= 0) {
+      seq_cols.push_back(i);
+      seq_members.push_back(col_member[i]);
+    }
+  if (seq_members.empty()) {
+    std::cout << "No sample of " << o.pl_file << " is in the ped file." << std::endl;
+    return false;
+  }
+  famseq_model m;
+  famseq_ctx *ctx = make_ctx(o, ped, sequenced, m);
+  if (!ctx) return false;
+  std::ofstream fout(o.out_file.c_str());
+  fout << "##FORMAT=<ID=GPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
+          "calculated by individual-base Method\">" << std::endl;
+  fout << "##FORMAT=<ID=FPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
+          "calculated by FamSeqPro\">" << std::endl;
+  fout << "##FORMAT=<ID=FGT,Number=1,Type=String,Description=\"Genotype called by FamSeqPro\">" << std::endl;
+  fout << "##FS mutation rate=" << o.mrate << " " << std::endl;
+  fout << "##FS genotype frequency in pupulation: "; put_triple(fout, m.genoProbN); fout << std::endl;
+  fout << "#FORMAT\t";
+  for (uint32_t c : seq_cols) fout << names[c] << '\t';
+  fout << std::endl;
+
+  const size_t cap = batch_capacity(), k = seq_members.size();
+  vector<char> raw(cap * rec);
+  vector<uint8_t> flags(cap), status(cap);
+  vector<uint16_t> pl(cap * k * 3);
+  vector<double> gpp(cap * k * 3), fpp(cap * k * 3);
+  vector<int8_t> fgt(cap * k);
+  bool ok = true;
+  string line;
+  while (ok) {
+    fin.read(raw.data(), (std::streamsize)raw.size());
+    const size_t n = size_t(fin.gcount()) / rec;
+    if (n == 0) break;
+    for (size_t s = 0; s < n; s++) {  // de-interleave: flags[] and the PED-matched columns of pl[]
+      const char *r = raw.data() + s * rec;
+      flags[s] = uint8_t(r[0]);
+      for (size_t j = 0; j < k; j++) std::memcpy(&pl[(s * k + j) * 3], r + 1 + 6 * seq_cols[j], 6);
+    }
+    const int rc = famseq_bn_call_batch(ctx, (int64_t)n, nullptr, pl.data(), flags.data(), seq_members.data(), (int32_t)k,
+                                        gpp.data(), fpp.data(), fgt.data(), status.data());
+    if (rc != 0) {
+      std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx) << std::endl;
+      ok = false;
+      break;
+    }
+    for (size_t s = 0; s < n; s++) {
+      line.assign("PL:GPP:FPP:FGT\t");
+      for (size_t j = 0; j < k; j++) {
+        const uint16_t *p = &pl[(s * k + j) * 3];
+        char buf[48];
+        if (p[0] == 0xFFFF && p[1] == 0xFFFF && p[2] == 0xFFFF) std::snprintf(buf, sizeof buf, "NA");
+        else std::snprintf(buf, sizeof buf, "%u,%u,%u", p[0], p[1], p[2]);
+        line += buf;
+        if (status[s] & 3) {
+          line += ":NA:NA:NA\t";
+          continue;
+        }
+        const double *g = &gpp[(s * k + j) * 3], *f = &fpp[(s * k + j) * 3];
+        line += ':';
+        put_double(line, g[0]); line += ',';
+        put_double(line, g[1]); line += ',';
+        put_double(line, g[2]); line += ':';
+        put_double(line, f[0]); line += ',';
+        put_double(line, f[1]); line += ',';
+        put_double(line, f[2]); line += ':';
+        const int gt = fgt[s * k + j];
+        line += gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t");
+      }
+      fout << line << '\n';
+    }
+  }
+  famseq_destroy(ctx);
+  return ok;
+}
+
 // ---- VCF driver ----------------------------------------------------------------------------
 
 int chrom_number(const string &c) {  // file.cpp:321-343
@@ -458,7 +625,9 @@ bool run_vcf(const Options &o, const Ped &ped) {
     if (o.gXN.size() == 3) std::copy(o.gXN.begin(), o.gXN.end(), m.genoProbXN);
     if (o.gXK.size() == 3) std::copy(o.gXK.begin(), o.gXK.end(), m.genoProbXK);
   }
-  std::ofstream fout(o.out_file.c_str());
+  // pack mode writes a binary file: the text header goes nowhere
+  std::ofstream fout;
+  if (!o.pack_mode) fout.open(o.out_file.c_str());
 
   // ---- header (file.cpp:143-196): lines are echoed with a one-line lag
   auto format_tags = [&](bool fallback) {
@@ -547,8 +716,19 @@ bool run_vcf(const Options &o, const Ped &ped) {
     for (auto &v : loc) std::sort(v.begin(), v.end());
   }
 
-  famseq_ctx *ctx = make_ctx(o, ped, sequenced, m);
-  if (!ctx) return false;
+  PackWriter packer;
+  famseq_ctx *ctx = nullptr;
+  if (o.pack_mode) {
+    vector<string> names;
+    for (int c : seq_cols) names.push_back(head[9 + c]);
+    if (names.empty() || !packer.open(o.out_file, names)) {
+      std::cout << "Cannot write " << o.out_file << " (or no sample of the vcf file is in the ped file)." << std::endl;
+      return false;
+    }
+  } else {
+    ctx = make_ctx(o, ped, sequenced, m);
+    if (!ctx) return false;
+  }
   BatchCaller caller(ctx, ped.n(), seq_members, fout, batch_capacity());
   const PlTable pl;
   const size_t n_seq = seq_cols.size();
@@ -557,6 +737,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
   bool ok = true;
 
   auto echo = [&](const vector<string> &t) {  // the "allLine" echo: 9 columns + sequenced samples
+    if (o.pack_mode) return;
     string s;
     for (int i = 0; i < 9; i++) s += t[i] + '\t';
     for (int c : seq_cols) s += t[9 + c] + '\t';
@@ -635,7 +816,18 @@ bool run_vcf(const Options &o, const Ped &ped) {
         b = e < end ? e + 1 : end;
       }
     }
+    if (o.pack_mode) {
+      if (integral) packer.add(flags, pl16.data());
+      else packer.skipped++;
+      continue;
+    }
     ok = caller.site(std::move(r), lk, integral ? pl16.data() : nullptr, flags);
+  }
+  if (o.pack_mode) {
+    std::cout << packer.n_sites << " sites packed";
+    if (packer.skipped) std::cout << ", " << packer.skipped << " skipped (PL/GL field is not a plain integer)";
+    std::cout << std::endl;
+    return packer.close();
   }
   ok = ok && caller.flush();
   famseq_destroy(ctx);
@@ -739,6 +931,8 @@ void help() {
             << "-genoProbXN\tPr(G) for chromosome X of males, not in dbSNP. Default 0.999 0.001." << std::endl
             << "-genoProbXK\tPr(G) for chromosome X of males, in dbSNP. Default 0.5 0.5." << std::endl
             << "-LRC\t\tLikelihood ratio criterion for the single-sample shortcut. Default 1." << std::endl
+            << "pack\t\tFamSeq pack -vcfFile f -pedFile p -output f.fspl: write the computable sites as packed integer PLs." << std::endl
+            << "PL\t\tFamSeq PL -plFile f.fspl -pedFile p -output o: call variants from a packed PL file." << std::endl
             << "Environment: FAMSEQ_DEVICE (GPU index, default 0), FAMSEQ_BATCH (sites per GPU batch)." << std::endl;
 }
 
@@ -754,9 +948,9 @@ int main(int argc, char **argv) {
     help();
     return 0;
   }
-  if (mode != "vcf" && mode != "LK") {
+  if (mode != "vcf" && mode != "LK" && mode != "pack" && mode != "PL") {
     std::cout << "Cannot recognize the input type: \"" << argv[1] << "\"." << std::endl
-              << "The input type can only be vcf or LK" << std::endl << std::endl
+              << "The input type can only be vcf or LK (or pack / PL for the packed binary PL format)" << std::endl << std::endl
               << "Type FamSeq -h for help." << std::endl;
     return -1;
   }
@@ -766,7 +960,9 @@ int main(int argc, char **argv) {
     return -1;
   }
   Options o;
-  o.lk_mode = mode == "LK";
+  o.lk_mode = mode == "LK" || mode == "PL";
+  o.pl_mode = mode == "PL";
+  o.pack_mode = mode == "pack";
   const int rc = parse_options(argc, argv, o);
   if (rc < 0) return -1;
   if (rc > 0)
@@ -782,6 +978,6 @@ int main(int argc, char **argv) {
     std::cout << "Cannot read Ped file: " << o.ped_file << "." << std::endl << "Cannot set family." << std::endl;
     return -1;
   }
-  const bool ok = o.lk_mode ? run_lk(o, ped) : run_vcf(o, ped);
+  const bool ok = o.pl_mode ? run_pl(o, ped) : (o.lk_mode ? run_lk(o, ped) : run_vcf(o, ped));
   return ok ? 0 : -1;
 }

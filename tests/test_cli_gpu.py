@@ -137,3 +137,36 @@ def test_usage_and_errors(tmp_path):
     p = subprocess.run([CLI, "vcf", "-vcfFile", TD + "/probe.vcf", "-pedFile", TD + "/probe.ped", "-output", str(tmp_path / "x"),
                         "-method", "2"], capture_output=True, text=True)
     assert p.returncode == 255 and "-method 1" in p.stdout
+
+
+def result_fields(path, prefix):
+    """[(GPP, FPP, FGT) per sample] per result line."""
+    out = []
+    for line in open(path):
+        if line.startswith("#") or ":GPP:FPP:FGT" not in line:
+            continue
+        t = line.rstrip("\n").split("\t")
+        samples = [x for x in (t[9:] if prefix == "vcf" else t[1:]) if x]
+        out.append([tuple(x.split(":")[-3:]) for x in samples])
+    return out
+
+
+@pytest.mark.parametrize("vcf,ped", [("test_subset.vcf", "fam01.ped"), ("test_subset.vcf", "fam04.ped"), ("probe.vcf", "probe.ped")])
+def test_packed_pl_pipeline_gives_the_vcf_results(vcf, ped, tmp_path):
+    """vcf -> `FamSeq pack` -> .fspl -> `FamSeq PL`: same GPP/FPP/FGT as `FamSeq vcf` on the sites
+    that are packable (integer PLs)."""
+    v, p, b, o = tmp_path / "v.vcf", tmp_path / "p.txt", tmp_path / "x.fspl", TD + "/" + ped
+    run_cli(["vcf", "-vcfFile", TD + "/" + vcf, "-pedFile", o], v)
+    r = subprocess.run([CLI, "pack", "-vcfFile", TD + "/" + vcf, "-pedFile", o, "-output", str(b)], capture_output=True, text=True)
+    assert r.returncode == 0
+    run_cli(["PL", "-plFile", str(b), "-pedFile", o], p)
+    a = [x for x, line in zip(result_fields(v, "vcf"), [l for l in open(v) if ":GPP:FPP:FGT" in l and not l.startswith("#")])
+         if "GT:GL" not in line]
+    got = result_fields(p, "pl")
+    assert len(got) == len(a) > 0
+    for x, y in zip(a, got):
+        assert len(x) == len(y)
+        for (g1, f1, t1), (g2, f2, t2) in zip(x, y):
+            assert t1 == t2
+            for u, w in zip(g1.split(",") + f1.split(","), g2.split(",") + f2.split(",")):
+                assert num_close(u, w), (x, y)

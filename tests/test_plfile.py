@@ -1,0 +1,86 @@
+"""Packed PL file format: `FamSeq pack` (host only, no GPU needed) writes what the vcf driver
+would compute, Python reads/writes the same bytes."""
+import os
+import subprocess
+
+import numpy as np
+
+from famseq_amd import plfile
+from famseq_amd.pedigree import read_ped
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "bin", "FamSeq")
+TD = os.path.join(ROOT, "tests", "golden", "testdata")
+
+
+def python_sites(vcf, ped):
+    """Integer PLs of the computable sites, by the reference's site rules (file.cpp:362-555)."""
+    names, out_flags, out_pl = [], [], []
+    for line in open(vcf):
+        line = line.rstrip("\n")
+        if len(line) < 2:
+            break
+        if line.startswith("##"):
+            continue
+        t = line.split("\t")
+        if line.startswith("#CHROM"):
+            cols = [i for i, c in enumerate(t[9:]) if c in ped.names]
+            names = [t[9 + i] for i in cols]
+            continue
+        if t[3] in (".", "-") or len(t[3]) != 1 or len(t[4]) != 1 or t[0] in ("Y", "chrY", "MT"):
+            continue
+        c = t[0][3:] if t[0].startswith("chr") else t[0]
+        is_x = t[0] in ("X", "chrX", "CHRX")
+        if not ((c.isdigit() and 0 < int(c) < 23) or is_x):
+            continue
+        fmt = t[8].split(":")
+        if all(len(t[9 + i]) < 5 for i in cols):
+            continue
+        ipl = max([k for k, key in enumerate(fmt) if key in ("PL", "GL")], default=-1)
+        if ipl < 0:
+            continue
+        row, integral = [], True
+        for i in cols:
+            f = t[9 + i]
+            sub = f.split(":")
+            if len(f) < 5 or len(sub) != len(fmt):
+                row.append([0xFFFF] * 3)
+                continue
+            vals = sub[ipl].split(",")[:3]
+            if not all(v.isdigit() for v in vals):
+                integral = False
+                break
+            row.append([min(int(v), 65534) for v in vals])
+        if integral:
+            out_flags.append((1 if t[2] != "." else 0) | (2 if is_x else 0))
+            out_pl.append(row)
+    return names, np.array(out_flags, np.uint8), np.array(out_pl, np.uint16)
+
+
+def test_pack_matches_python_site_rules(tmp_path):
+    for vcf, ped in (("test_subset.vcf", "fam01.ped"), ("test_subset.vcf", "fam04.ped"), ("probe.vcf", "probe.ped")):
+        out = tmp_path / "x.fspl"
+        p = subprocess.run([CLI, "pack", "-vcfFile", os.path.join(TD, vcf), "-pedFile", os.path.join(TD, ped),
+                            "-output", str(out)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout + p.stderr
+        names, flags, pl = plfile.read_plfile(str(out))
+        want = python_sites(os.path.join(TD, vcf), read_ped(os.path.join(TD, ped)))
+        assert names == want[0]
+        assert np.array_equal(flags, want[1]) and np.array_equal(pl, want[2])
+        if vcf == "probe.vcf":
+            assert "skipped" in p.stdout  # the GL line is not packable
+            assert int(np.sum(np.all(pl == 0xFFFF, axis=2))) >= 1  # the missing sample at POS 600
+        if ped == "fam01.ped":
+            assert pl.max() == 65534  # test.vcf holds a PL of 84692 for ind03: clamped (exactly 0 either way)
+
+
+def test_python_writer_roundtrip(tmp_path):
+    rng = np.random.RandomState(2)
+    pl = rng.randint(0, 65536, size=(1000, 5, 3)).astype(np.uint16)
+    flags = rng.randint(0, 4, 1000).astype(np.uint8)
+    path = str(tmp_path / "r.fspl")
+    plfile.write_plfile(path, ["s%d" % i for i in range(5)], flags, pl)
+    for mm in (True, False):
+        n, f, p = plfile.read_plfile(path, mmap=mm)
+        assert n == ["s0", "s1", "s2", "s3", "s4"] and np.array_equal(f, flags) and np.array_equal(p, pl)
+    assert os.path.getsize(path) == 24 + 5 * 32 + 1000 * 31
