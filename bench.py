@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {  # name -> (BASELINE.json config number, default sites per GPU)
     "ped5": (1, 1_000_000),
     "ped10": (2, 10_000_000),
-    "ped15": (4, 20_000),
+    "ped15": (4, 131_072),
 }
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TOPS = 39.3   # fp64 vector instructions-lanes/s: 78.6 TFLOP/s (FMA = 2 flops) / 2

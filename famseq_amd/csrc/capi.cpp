@@ -46,7 +46,7 @@ struct famseq_ctx {
   int lane_blocks_per_cu = 0;
   bool lane_failed = false;
   std::string lane_error;
-  int64_t lane_min_sites = 16384;
+  int64_t lane_min_sites = 32768;  // below this the lane kernel cannot fill 256 CUs x 4 SIMDs; the team kernel is faster
   // device constants
   uint32_t *d_img = nullptr;
   double *d_tc = nullptr;
