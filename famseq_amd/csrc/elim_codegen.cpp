@@ -18,6 +18,7 @@
 // to the CPU reference).  One member per connected component carries the reference's 1e7 scale.
 #include "elim_codegen.h"
 
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <numeric>
@@ -238,7 +239,10 @@ bool elim_supported(const famseq_model &m, std::string *why) {
   return build_graph(m, g, why);
 }
 
-int elim_block_threads(const famseq_model &m) { return m.n_members <= 10 ? 256 : 128; }
+int elim_block_threads(const famseq_model &m) {
+  if (const char *e = std::getenv("FAMSEQ_ELIM_BT")) return std::atoi(e);  // tuning aid
+  return m.n_members <= 10 ? 256 : 128;
+}
 
 // The part every generated engine shares: I/O staging through padded LDS rows, the single
 // posterior, the shortcut vote and the status byte.  `body` runs for sites that need the full
@@ -359,7 +363,7 @@ std::string elim_source(const famseq_model &m) {
   const int bt = elim_block_threads(m);
   return kernel_shell(m, "famseq_elim",
                       "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families", Emitter(m, g).body(),
-                      bt, bt / 128, /*regs_l=*/false);
+                      bt, m.n_members <= 10 ? 2 : 1, /*regs_l=*/false);
 }
 
 }  // namespace famseq
