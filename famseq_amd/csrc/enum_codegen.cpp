@@ -16,6 +16,8 @@
 #include "enum_codegen.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <functional>
 #include <sstream>
 #include <stdexcept>
 #include <vector>
@@ -83,14 +85,20 @@ Shape choose_shape(const famseq_model &m, int cap) {
   Shape s;
   s.N = N;
   s.upos.assign(N, -1);
-  for (int i : order) {
-    if (inU[i]) {
-      s.upos[i] = (int)s.unrolled.size();
-      s.unrolled.push_back(i);
-    } else {
-      s.outer.push_back(i);
-    }
-  }
+  for (int i : order)
+    if (!inU[i]) s.outer.push_back(i);
+  // Unrolled members in depth-first order (parents before children, each subtree contiguous):
+  // the block sums below a level then depend on as few upper digits as possible.
+  std::function<void(int)> place = [&](int i) {
+    if (!inU[i] || s.upos[i] >= 0) return;
+    if (m.mother[i] >= 0)
+      for (int par : {m.mother[i], m.father[i]})
+        if (inU[par] && s.upos[par] < 0) return;  // placed later, from its other parent
+    s.upos[i] = (int)s.unrolled.size();
+    s.unrolled.push_back(i);
+    for (int c : kids[i]) place(c);
+  };
+  for (int i : order) place(i);
   return s;
 }
 
@@ -99,6 +107,7 @@ class Gen {
   Gen(const famseq_model &m, const Shape &s) : m_(m), s_(s), nu_((int)s.unrolled.size()) {}
 
   std::string body() {
+    compute_deps();
     o_ << "      // outer (looped) members:";
     for (int p : s_.outer) o_ << " " << p;
     o_ << " | unrolled block:";
@@ -168,13 +177,29 @@ class Gen {
     }
     return n;
   }
-  std::string s_name(const std::vector<int> &dig) const {  // sum over the deepest member's own digit
-    const int p = s_.unrolled[nu_ - 1];
-    std::string n = "S" + num(p);
-    if (m_.mother[p] >= 0) {
-      if (s_.upos[m_.mother[p]] >= 0) n += "m" + num(dig[s_.upos[m_.mother[p]]]);
-      if (s_.upos[m_.father[p]] >= 0) n += "f" + num(dig[s_.upos[m_.father[p]]]);
+  // dep_[k]: unrolled levels < k whose digits the block sums of levels >= k depend on
+  std::vector<std::vector<int>> dep_;
+
+  void compute_deps() {
+    dep_.assign(nu_ + 1, {});
+    for (int k = nu_ - 1; k >= 0; --k) {
+      std::vector<char> in(nu_, 0);
+      for (int j = k; j < nu_; ++j) {
+        const int p = s_.unrolled[j];
+        if (m_.mother[p] < 0) continue;
+        for (int par : {m_.mother[p], m_.father[p]})
+          if (s_.upos[par] >= 0 && s_.upos[par] < k) in[s_.upos[par]] = 1;
+      }
+      for (int l = 0; l < k; ++l)
+        if (in[l]) dep_[k].push_back(l);
     }
+  }
+  // Q<k>[digits of dep_[k]] = sum over the configurations of levels k.. of prod w: the total
+  // weight below a node, per unit of prefix.  Q<nu> = 1.
+  std::string q_name(int k, const std::vector<int> &dig) const {
+    if (k >= nu_) return "1.0";
+    std::string n = "Q" + num(k);
+    for (int l : dep_[k]) n += "_" + num(l) + "d" + num(dig[l]);
     return n;
   }
 
@@ -191,46 +216,53 @@ class Gen {
           for (int g = 0; g < 3; ++g)
             o_ << ind << "const double w" << p << "_" << g << suffix << " = tcf["
                << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * l" << p << "_" << g << ";\n";
-          if (k == nu_ - 1)
-            o_ << ind << "const double S" << p << suffix << " = (w" << p << "_0" << suffix << " + w" << p << "_1" << suffix
-               << ") + w" << p << "_2" << suffix << ";\n";
         }
+    }
+    // block sums, deepest level first
+    for (int k = nu_ - 1; k >= 0; --k) {
+      const int nd = (int)dep_[k].size();
+      std::vector<int> dig(nu_, 0);
+      for (int code = 0; code < pow3(nd); ++code) {
+        int c = code;
+        for (int l : dep_[k]) {
+          dig[l] = c % 3;
+          c /= 3;
+        }
+        std::string e;
+        for (int g = 0; g < 3; ++g) {
+          dig[k] = g;
+          const std::string w = w_name(k, g, dig), q = q_name(k + 1, dig);
+          if (q == "1.0") e = e.empty() ? w : "(" + e + " + " + w + ")";
+          else e = e.empty() ? "(" + w + " * " + q + ")" : "__builtin_fma(" + w + ", " + q + ", " + e + ")";
+        }
+        o_ << ind << "const double " << q_name(k, dig) << " = " << e << ";\n";
+      }
     }
   }
 
-  // emits level k of the unrolled block; returns the name of the subtree total
-  std::string level(int k, const std::string &P, std::vector<int> &dig, const std::string &ind) {
+  // Level k of the unrolled block: one product per child prefix, one FMA into the level's own
+  // marginal with the child's block sum; the deepest level forms each configuration's weight in
+  // the FMA that adds it to that member's marginal.
+  void level(int k, const std::string &P, std::vector<int> &dig, const std::string &ind) {
     const int p = s_.unrolled[k];
-    if (k == nu_ - 1) {  // deepest member: one FMA per configuration
+    if (k == nu_ - 1) {
       for (int g = 0; g < 3; ++g)
         o_ << ind << "b" << p << "_" << g << " = __builtin_fma(" << P << ", " << w_name(k, g, dig) << ", b" << p << "_" << g
            << ");\n";
       o_ << ind << "asm volatile(\"\" : \"+v\"(b" << p << "_0), \"+v\"(b" << p << "_1), \"+v\"(b" << p << "_2), \"+v\"(" << P
          << "));\n";
-      return "";
+      return;
     }
-    std::string subs[3];
     for (int g = 0; g < 3; ++g) {
       dig[k] = g;
       const std::string pg = "p" + num(uid_++);
-      o_ << ind << "double " << pg << " = " << P << " * " << w_name(k, g, dig) << ";\n";
-      std::string sub;
-      if (k == nu_ - 2) {
-        sub = "s" + num(uid_++);
-        o_ << ind << "double " << sub << " = " << pg << " * " << s_name(dig) << ";\n"
-           << ind << "asm volatile(\"\" : \"+v\"(" << pg << "), \"+v\"(" << sub << "));\n";
-        level(k + 1, pg, dig, ind);
-      } else {
-        o_ << ind << "asm volatile(\"\" : \"+v\"(" << pg << "));\n";
-        sub = level(k + 1, pg, dig, ind);
-      }
-      o_ << ind << "b" << p << "_" << g << " += " << sub << ";\n"
-         << ind << "asm volatile(\"\" : \"+v\"(" << P << "), \"+v\"(b" << p << "_" << g << "), \"+v\"(" << sub << "));\n";
-      subs[g] = sub;
+      o_ << ind << "double " << pg << " = " << P << " * " << w_name(k, g, dig) << ";\n"
+         << ind << "b" << p << "_" << g << " = __builtin_fma(" << pg << ", " << q_name(k + 1, dig) << ", b" << p << "_" << g
+         << ");\n"
+         << ind << "asm volatile(\"\" : \"+v\"(" << pg << "), \"+v\"(b" << p << "_" << g << "));\n";
+      level(k + 1, pg, dig, ind);
+      o_ << ind << "asm volatile(\"\" : \"+v\"(" << P << "), \"+v\"(b" << p << "_" << g << "));\n";
     }
-    const std::string tot = "t" + num(uid_++);
-    o_ << ind << "double " << tot << " = (" << subs[0] << " + " << subs[1] << ") + " << subs[2] << ";\n";
-    return tot;
   }
 
   void block(const std::string &P, const std::string &acc_parent) {
@@ -239,23 +271,19 @@ class Gen {
     const std::string in2 = ind + "  ";
     tables(in2);
     std::vector<int> dig(nu_, 0);
-    std::string tot;
     o_ << in2 << "double Pb = " << P << ";\n";
-    if (nu_ == 1) {
-      tot = "tb";
-      o_ << in2 << "const double tb = Pb * " << s_name(dig) << ";\n";
-      level(0, "Pb", dig, in2);
-    } else {
-      tot = level(0, "Pb", dig, in2);
-    }
-    if (!acc_parent.empty()) o_ << in2 << acc_parent << " += " << tot << ";\n";
+    if (!acc_parent.empty()) o_ << in2 << acc_parent << " += Pb * " << q_name(0, dig) << ";\n";
+    level(0, "Pb", dig, in2);
     o_ << ind << "}\n";
   }
 };
 
 }  // namespace
 
-int enumgen_block_threads(const famseq_model &m) { return m.n_members <= 10 ? 256 : 128; }
+int enumgen_block_threads(const famseq_model &m) {
+  if (const char *e = std::getenv("FAMSEQ_LANE_BT")) return std::atoi(e);  // tuning aid
+  return m.n_members <= 10 ? 256 : 128;
+}
 
 std::string enumgen_source(const famseq_model &m) {
   const Shape s = choose_shape(m, 6);
@@ -263,7 +291,9 @@ std::string enumgen_source(const famseq_model &m) {
   const int bt = enumgen_block_threads(m);
   std::string what = "3^N enumeration, lane per site, " + std::to_string(s.outer.size()) + " looped + " +
                      std::to_string(s.unrolled.size()) + " unrolled members";
-  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s).body(), bt, bt / 128, /*regs_l=*/true);
+  int min_waves = bt / 128;
+  if (const char *e = std::getenv("FAMSEQ_LANE_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
+  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s).body(), bt, min_waves, /*regs_l=*/true);  // LDS-resident likelihoods measured 17% slower
 }
 
 }  // namespace famseq
