@@ -26,6 +26,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "famseq_hip.h"
@@ -79,6 +80,25 @@ struct PlTable {
     return std::pow(10.0, -std::fabs(x) / 10.0);
   }
 };
+
+// Text formatting is the slowest part of the pipeline (printf-style %g per number); the records
+// of a flushed batch are independent, so they are formatted on all host cores and written in order.
+template <class F>
+void parallel_for(size_t n, F f) {
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char *e = std::getenv("FAMSEQ_THREADS")) t = (unsigned)std::atoi(e);
+  t = std::max(1u, std::min(t, 32u));
+  if (n < 2048 || t == 1) {
+    for (size_t i = 0; i < n; ++i) f(i);
+    return;
+  }
+  vector<std::thread> pool;
+  for (unsigned k = 0; k < t; ++k)
+    pool.emplace_back([=] {
+      for (size_t i = n * k / t, e = n * (k + 1) / t; i < e; ++i) f(i);
+    });
+  for (std::thread &th : pool) th.join();
+}
 
 // ---- options -----------------------------------------------------------------------------
 
@@ -359,12 +379,13 @@ class BatchCaller {
         return false;
       }
     }
-    string line;
-    for (Record &r : q_) {
+    vector<string> lines(q_.size());
+    parallel_for(q_.size(), [&](size_t i) {
+      const Record &r = q_[i];
+      string &line = lines[i];
       line.assign(r.text);
       if (r.site >= 0) {
         if (status_[r.site] & 3) {  // file.cpp:607-620
-          std::cout << "Warning: this variant hasn't been calculated: " << std::endl << r.raw << std::endl;
           for (const string &f : r.fail_fields) line += f + ":NA:NA:NA\t";
         } else {
           for (size_t j = 0; j < k; ++j) {
@@ -381,7 +402,12 @@ class BatchCaller {
           }
         }
       }
-      out_ << line << '\n';
+      line += '\n';
+    });
+    for (size_t i = 0; i < q_.size(); ++i) {
+      if (q_[i].site >= 0 && (status_[q_[i].site] & 3))
+        std::cout << "Warning: this variant hasn't been calculated: " << std::endl << q_[i].raw << std::endl;
+      out_.write(lines[i].data(), (std::streamsize)lines[i].size());
     }
     q_.clear();
     lk_.clear();
@@ -549,7 +575,6 @@ bool run_pl(const Options &o, const Ped &ped) {
   vector<double> gpp(cap * k * 3), fpp(cap * k * 3);
   vector<int8_t> fgt(cap * k);
   bool ok = true;
-  string line;
   while (ok) {
     fin.read(raw.data(), (std::streamsize)raw.size());
     const size_t n = size_t(fin.gcount()) / rec;
@@ -566,7 +591,9 @@ bool run_pl(const Options &o, const Ped &ped) {
       ok = false;
       break;
     }
-    for (size_t s = 0; s < n; s++) {
+    vector<string> lines(n);
+    parallel_for(n, [&](size_t s) {
+      string &line = lines[s];
       line.assign("PL:GPP:FPP:FGT\t");
       for (size_t j = 0; j < k; j++) {
         const uint16_t *p = &pl[(s * k + j) * 3];
@@ -589,8 +616,9 @@ bool run_pl(const Options &o, const Ped &ped) {
         const int gt = fgt[s * k + j];
         line += gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t");
       }
-      fout << line << '\n';
-    }
+      line += '\n';
+    });
+    for (size_t s = 0; s < n; s++) fout.write(lines[s].data(), (std::streamsize)lines[s].size());
   }
   famseq_destroy(ctx);
   return ok;

@@ -235,3 +235,22 @@ def test_deep_enumeration_ped15_and_max_members():
     assert np.array_equal(st, ref[2])
     np.testing.assert_allclose(post, ref[0], rtol=RTOL)
     ctx.close()
+
+
+def test_degenerate_pedigrees():
+    """One member; two unrelated members; a trio whose only sequenced member is the child."""
+    for ids, mids, fids, gen, names in (([1], [0], [0], [1], ["a"]),
+                                        ([1, 2], [0, 0], [0, 0], [2, 1], ["a", "b"]),
+                                        ([1, 2, 3], [0, 0, 2], [0, 0, 1], [1, 2, 1], ["NA", "NA", "c"])):
+        ped = fs.Pedigree(ids, mids, fids, gen, names)
+        mo, fa = ped.relations()
+        lk, flags = fs.synth.gen_batch(mo, fa, 40, 61)
+        lk[:, ped.sequenced == 0, :] = 1.0
+        flags[::3] |= 2
+        ref = oracle.OracleModel(ids, mids, fids, gen, ped.sequenced).bn_batch(lk, flags)
+        for opt in (dict(enum_impl=0), dict(enum_impl=1), dict(engine=fs.ENGINE_ELIM)):
+            ctx = fs.Context(fs.make_model(ped), **opt)
+            post, single, st = ctx.bn_batch(lk, flags)
+            ctx.close()
+            assert np.array_equal(st, ref[2]) and np.array_equal(single, ref[1])
+            np.testing.assert_allclose(post, ref[0], rtol=RTOL, atol=0)
