@@ -255,6 +255,9 @@ int elim_block_threads(const famseq_model &m) {
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l) {
   const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1;
+  // Prefetching the next chunk costs W3 doubles of registers next to the W3 marginals; measured on
+  // MI355X it pays up to 7 members (ped5: +14 %) and spills beyond (ped10: -35 %).
+  const bool prefetch = !regs_l && N <= 7;
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
@@ -287,13 +290,22 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  const double kNaN = __builtin_nan(\"\");\n"
     << "  double *row = s_io + tid * ROW;\n"
     << "  const volatile double *lrow = row;  // (regs_l = false) forces a fresh LDS read per use\n"
+    << "  double pre[W3];  // (regs_l = false) this lane's share of the NEXT chunk, loaded ahead\n"
+    << "  bool have_pre = false;\n"
     << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
     << "    const long site0 = ch * BT;\n"
     << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
     << "    const int nel = ns * W3;\n"
-    << "    LDS_BARRIER();\n"
-    << "    STAGE(s_io[a] = lk_g[site0 * W3 + e]);\n"
-    << "    LDS_BARRIER();\n"
+    << "    LDS_BARRIER();\n";
+  if (regs_l) {
+    s << "    STAGE(s_io[a] = lk_g[site0 * W3 + e]);\n";
+  } else if (prefetch) {
+    // the next chunk's rows were requested during the previous chunk's output phases
+    s << "    if (have_pre) { STAGE(s_io[a] = pre[k]); } else { STAGE(s_io[a] = lk_g[site0 * W3 + e]); }\n";
+  } else {
+    s << "    STAGE(s_io[a] = lk_g[site0 * W3 + e]);\n";
+  }
+  s << "    LDS_BARRIER();\n"
     << "    const int fl = (tid < ns && flags_g) ? (flags_g[site0 + tid] & 3) : 0;\n"
     << "    const double *tcf = s_tc + fl * 108;\n"
     << "    bool single_fail = false, full = false, bn_fail = false;\n";
@@ -339,7 +351,18 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     single_pass(true, false);
     s << "    double q[W3];\n"
       << "    if (full && !single_fail) {\n"
-      << body << "    }\n";
+      << body << "    }\n"
+      ;
+    if (prefetch)
+      // software prefetch: issue the next chunk's loads now; they stay in flight while this
+      // chunk's two output phases run (the barriers below do not wait for vmcnt)
+      s << "    have_pre = ch + 1 < c_hi;\n"
+      << "    if (have_pre) {\n"
+      << "      const long site1 = site0 + BT;\n"
+      << "      const int nel1 = (n_sites - site1 < BT ? (int)(n_sites - site1) : BT) * W3;\n"
+      << "      { int e = tid;\n"
+      << "        _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { pre[k] = e < nel1 ? lk_g[site1 * W3 + e] : 0.0; e += BT; } }\n"
+      << "    }\n";
     single_pass(false, true);  // now the single posterior may take the row over
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << "    LDS_BARRIER();\n"
