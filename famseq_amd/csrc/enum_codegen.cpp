@@ -286,7 +286,9 @@ int enumgen_block_threads(const famseq_model &m) {
 }
 
 std::string enumgen_source(const famseq_model &m) {
-  const Shape s = choose_shape(m, 6);
+  int cap = 6;
+  if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);  // tuning aid
+  const Shape s = choose_shape(m, cap);
   if (s.unrolled.empty()) throw std::runtime_error("enumeration codegen: empty unrolled set");
   const int bt = enumgen_block_threads(m);
   std::string what = "3^N enumeration, lane per site, " + std::to_string(s.outer.size()) + " looped + " +
