@@ -108,15 +108,29 @@ class Gen {
 
   std::string body() {
     compute_deps();
+    const int no = (int)s_.outer.size(), row_len = (3 * s_.N) | 1;
+    l_in_lds_ = 6 * no <= row_len;
     o_ << "      // outer (looped) members:";
     for (int p : s_.outer) o_ << " " << p;
     o_ << " | unrolled block:";
     for (int p : s_.unrolled) o_ << " " << p;
     o_ << " (" << pow3(nu_) << " configurations per outer step)\n";
-    for (int p = 0; p < s_.N; ++p)
+    // The lane's LDS row is idle between the single-posterior store and the final write-back:
+    // the looped members' marginal accumulators (touched once per iteration of their own loop)
+    // and, when they fit, their likelihoods live there instead of in registers, which keeps the
+    // unrolled block free of scratch traffic.
+    for (int k = 0; k < no; ++k)
+      for (int g = 0; g < 3; ++g) {
+        o_ << "      row[" << 3 * k + g << "] = 0;\n";
+        if (l_in_lds_) o_ << "      row[" << 3 * no + 3 * k + g << "] = l" << s_.outer[k] << "_" << g << ";\n";
+      }
+    for (int p : s_.unrolled)
       o_ << "      double b" << p << "_0 = 0, b" << p << "_1 = 0, b" << p << "_2 = 0;\n";
     o_ << "      const double P_root = 10000000.0;\n";  // family.cpp:911
     outer_level(0, "P_root", "");
+    for (int k = 0; k < no; ++k)
+      o_ << "      const double b" << s_.outer[k] << "_0 = row[" << 3 * k << "], b" << s_.outer[k] << "_1 = row[" << 3 * k + 1
+         << "], b" << s_.outer[k] << "_2 = row[" << 3 * k + 2 << "];\n";
     for (int p = 0; p < s_.N; ++p)
       o_ << "      { const double s = (b" << p << "_0 + b" << p << "_1) + b" << p << "_2; if (s <= 0) bn_fail = true;\n"
          << "        row[" << 3 * p << "] = b" << p << "_0 / s; row[" << 3 * p + 1 << "] = b" << p << "_1 / s; row["
@@ -130,6 +144,7 @@ class Gen {
   const int nu_;
   std::ostringstream o_;
   int uid_ = 0;
+  bool l_in_lds_ = false;
 
   static int pow3(int e) {
     int r = 1;
@@ -154,15 +169,16 @@ class Gen {
       return;
     }
     const int p = s_.outer[k];
+    const int no = (int)s_.outer.size();
     const std::string g = "g" + num(p), ind(6 + 2 * k, ' ');
+    const std::string lk_g = l_in_lds_ ? "row[" + num(3 * no + 3 * (int)k) + " + " + g + "]"
+                                       : "(" + g + " == 0 ? l" + num(p) + "_0 : (" + g + " == 1 ? l" + num(p) + "_1 : l" + num(p) + "_2))";
     o_ << ind << "for (int " << g << " = 0; " << g << " < 3; ++" << g << ") {\n"
-       << ind << "  const double f" << p << " = tcf[" << t_index(p, g, -1, -1) << "] * (" << g << " == 0 ? l" << p
-       << "_0 : (" << g << " == 1 ? l" << p << "_1 : l" << p << "_2));\n"
+       << ind << "  const double f" << p << " = tcf[" << t_index(p, g, -1, -1) << "] * " << lk_g << ";\n"
        << ind << "  const double P" << p << " = " << P << " * f" << p << ";\n"
        << ind << "  double acc" << p << " = 0;\n";
     outer_level(k + 1, "P" + num(p), "acc" + num(p));
-    o_ << ind << "  if (" << g << " == 0) b" << p << "_0 += acc" << p << "; else if (" << g << " == 1) b" << p
-       << "_1 += acc" << p << "; else b" << p << "_2 += acc" << p << ";\n";
+    o_ << ind << "  row[" << 3 * (int)k << " + " << g << "] += acc" << p << ";\n";
     if (!acc_parent.empty()) o_ << ind << "  " << acc_parent << " += acc" << p << ";\n";
     o_ << ind << "}\n";
   }
