@@ -187,6 +187,7 @@ bool load_lane(famseq_ctx *c) {
       c->lane.path = jit_compile(src);
       return true;
     }
+    if (hipSetDevice(c->device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
     c->lane = jit_load(src, "famseq_enum_lane");
     int nb = 0;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->lane.fn, enumgen_block_threads(c->model), 0) != hipSuccess)

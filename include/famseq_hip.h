@@ -123,9 +123,10 @@ const char *famseq_plan_json(famseq_ctx *ctx);
 
 /* ---- the operator ---------------------------------------------------------- */
 
-/* Host buffers (pageable or pinned).  Blocking.  Stages through pinned memory in chunks
- * with H2D / kernel / D2H overlapped on separate HIP streams.  post_single and status may
- * be NULL.  Returns 0 or a negative error. */
+/* Host buffers (pageable or pinned).  Blocking.  Works in chunks on two HIP streams so that the
+ * H2D / D2H copies of one chunk overlap the kernel of the other.  post_single and status may be
+ * NULL.  Returns 0 or a negative error.  (The host link bounds this entry point: 722 B/site at
+ * N = 10; see famseq_bn_call_batch for the compact path.) */
 int famseq_bn_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, const uint8_t *flags,
                     double *post, double *post_single, uint8_t *status);
 
