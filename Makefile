@@ -39,6 +39,10 @@ $(CLI): $(CSRC)/host/famseq_cli.cpp include/famseq_hip.h $(LIB)
 	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ $(CSRC)/host/famseq_cli.cpp -Lfamseq_amd/lib -lfamseq_hip -lpthread \
 	    -Wl,-rpath,'$$ORIGIN/../famseq_amd/lib' -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
 
+# FETCH_SIZE / WRITE_SIZE calibration micro-benchmark (profiles/r01a/calib_fetch_write.txt)
+tools/calib_fetch: tools/calib_fetch.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+
 oracle:
 	$(MAKE) -C oracle all $(if $(wildcard /root/reference/src/family.cpp),ref,)
 
