@@ -262,8 +262,9 @@ def main():
             "config": {"workload": "%s: %d seeded synthetic sites per GPU, %d-member pedigree (3^%d = %d configs/site), "
                                    "-method 1 BN posterior, all sites full enumeration" % (a.workload, S, n, n, 3 ** n),
                        "sites_per_gpu": S, "global_sites": total_sites, "parallelism": "sites sharded x%d, no collective" % world,
-                       "plan": {k: plan[k] for k in ("L", "A", "J", "team_lanes", "teams_per_block", "block_threads",
-                                                     "lds_bytes", "blocks_per_cu")}},
+                       "engine": a.engine,
+                       "team_kernel_plan": {k: plan[k] for k in ("L", "A", "J", "team_lanes", "teams_per_block", "block_threads",
+                                                                 "lds_bytes", "blocks_per_cu")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms": kernel_ms,
