@@ -458,7 +458,18 @@ famseq_ctx *make_ctx(const Options &o, const Ped &ped, const vector<uint8_t> &se
   const char *dev = std::getenv("FAMSEQ_DEVICE");
   char err[512] = {0};
   famseq_ctx *ctx = famseq_create(&m, dev ? std::atoi(dev) : 0, err, sizeof err);
-  if (!ctx) std::cerr << "Cannot create the GPU context: " << err << std::endl;
+  if (!ctx) {
+    std::cerr << "Cannot create the GPU context: " << err << std::endl;
+    return nullptr;
+  }
+  // -method 2 (the reference's Elston-Stewart peeling, family.cpp:1126-1403) computes the same
+  // marginals exactly on loop-free pedigrees: here that is the sum-product engine.
+  if (o.method == 2 && famseq_set_option(ctx, "engine", FAMSEQ_ENGINE_ELIM) != 0) {
+    std::cout << "-method 2 needs a pedigree without loops: " << famseq_last_error(ctx) << std::endl
+              << "Use -method 1 for this pedigree." << std::endl;
+    famseq_destroy(ctx);
+    return nullptr;
+  }
   return ctx;
 }
 
@@ -949,7 +960,7 @@ void help() {
             << "-lkType\t\tn:normal(default); log10: log10 scaled; ln: ln scaled; PS: phred scaled." << std::endl
             << "-pedFile\tThe name of the file storing the pedigree information." << std::endl
             << "-output\t\tThe name of output file" << std::endl
-            << "-method\t\t1(default): Bayesian network (the only method of this build)." << std::endl
+            << "-method\t\t1(default): Bayesian network enumeration; 2: exact sum-product (loop-free pedigrees)." << std::endl
             << "-mRate\t\tMutation rate. The default value is 1e-7" << std::endl
             << "-v\t\tOnly record the position at which the genotype is not RR in the output file." << std::endl
             << "-a\t\tRecord all the position in the output file." << std::endl
@@ -996,9 +1007,9 @@ int main(int argc, char **argv) {
   if (rc > 0)
     std::cout << "There are some improper parameters in the command line. Some parameters are set to default."
               << std::endl;
-  if (o.method != 1) {
-    std::cout << "This build implements -method 1 (Bayesian network) only; methods 2 and 3 are not part of it."
-              << std::endl;
+  if (o.method == 3) {
+    std::cout << "This build implements -method 1 (Bayesian network) and -method 2 (exact sum-product on a loop-free "
+                 "pedigree, the result of Elston-Stewart peeling); -method 3 (MCMC) is not part of it." << std::endl;
     return -1;
   }
   Ped ped;

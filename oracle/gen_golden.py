@@ -223,6 +223,13 @@ def main():
                                "%s/ref_cli/probe_%s.vcf" % (OUT, tag), "-method", "1"] + extra, stdout=subprocess.DEVNULL)
     subprocess.check_call([oracle.REF_CLI, "vcf", "-vcfFile", noanchor, "-pedFile", probe_ped, "-output",
                            OUT + "/ref_cli/probe_noanchor.vcf"], stdout=subprocess.DEVNULL)
+    # -method 2 (Elston-Stewart) outputs: our CLI serves that flag with the exact sum-product engine
+    for tag, vcf_in, pedf in (("probe", probe, probe_ped), ("subset_fam01", sub, OUT + "/testdata/fam01.ped"),
+                              ("subset_fam04", sub, OUT + "/testdata/fam04.ped")):
+        subprocess.check_call([oracle.REF_CLI, "vcf", "-vcfFile", vcf_in, "-pedFile", pedf, "-output",
+                               "%s/ref_cli/%s_method2.vcf" % (OUT, tag), "-method", "2", "-a"], stdout=subprocess.DEVNULL)
+    subprocess.check_call([oracle.REF_CLI, "LK", "-lkFile", OUT + "/testdata/loftest.txt", "-pedFile", OUT + "/testdata/fam01.ped",
+                           "-output", OUT + "/ref_cli/loftest_fam01_method2.txt", "-method", "2"], stdout=subprocess.DEVNULL)
     # LK files in the three transformed likelihood types, from the first 20 loftest rows
     with open(OUT + "/testdata/loftest.txt") as f:
         lk_lines = [l.rstrip("\n") for l in f][:21]

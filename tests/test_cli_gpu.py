@@ -129,14 +129,26 @@ def test_small_batches_keep_output_order(tmp_path):
     assert_same_output(out, REF + "/subset_fam06_a.vcf")
 
 
+@pytest.mark.parametrize("tag,vcf,ped", [("probe", "probe.vcf", "probe.ped"), ("subset_fam01", "test_subset.vcf", "fam01.ped"),
+                                         ("subset_fam04", "test_subset.vcf", "fam04.ped")])
+def test_method_2_matches_reference_peeling(tag, vcf, ped, tmp_path):
+    """-method 2 (Elston-Stewart in the reference) is served by the exact sum-product engine."""
+    out = tmp_path / "o.vcf"
+    run_cli(["vcf", "-vcfFile", TD + "/" + vcf, "-pedFile", TD + "/" + ped, "-method", "2", "-a"], out)
+    assert_same_output(out, "%s/%s_method2.vcf" % (REF, tag))
+    out = tmp_path / "o.txt"
+    run_cli(["LK", "-lkFile", TD + "/loftest.txt", "-pedFile", TD + "/fam01.ped", "-method", "2"], out)
+    assert assert_same_output(out, REF + "/loftest_fam01_method2.txt") == 100
+
+
 def test_usage_and_errors(tmp_path):
     assert subprocess.run([CLI]).returncode == 255
     assert subprocess.run([CLI, "bogus"], capture_output=True).returncode == 255
     p = subprocess.run([CLI, "vcf", "-vcfFile", TD + "/probe.vcf", "-output", str(tmp_path / "x")], capture_output=True, text=True)
     assert p.returncode == 255 and "ped file must be set" in p.stdout
     p = subprocess.run([CLI, "vcf", "-vcfFile", TD + "/probe.vcf", "-pedFile", TD + "/probe.ped", "-output", str(tmp_path / "x"),
-                        "-method", "2"], capture_output=True, text=True)
-    assert p.returncode == 255 and "-method 1" in p.stdout
+                        "-method", "3"], capture_output=True, text=True)
+    assert p.returncode == 255 and "-method 3" in p.stdout
 
 
 def result_fields(path, prefix):
