@@ -257,7 +257,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
   const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1;
   // Prefetching the next chunk costs W3 doubles of registers next to the W3 marginals; measured on
   // MI355X it pays up to 7 members (ped5: +14 %) and spills beyond (ped10: -35 %).
-  const bool prefetch = !regs_l && N <= 7;
+  const bool prefetch = N <= 7;
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
@@ -290,16 +290,14 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  const double kNaN = __builtin_nan(\"\");\n"
     << "  double *row = s_io + tid * ROW;\n"
     << "  const volatile double *lrow = row;  // (regs_l = false) forces a fresh LDS read per use\n"
-    << "  double pre[W3];  // (regs_l = false) this lane's share of the NEXT chunk, loaded ahead\n"
+    << "  double pre[W3];  // (prefetch) this lane's share of the NEXT chunk, loaded ahead\n"
     << "  bool have_pre = false;\n"
     << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
     << "    const long site0 = ch * BT;\n"
     << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
     << "    const int nel = ns * W3;\n"
     << "    LDS_BARRIER();\n";
-  if (regs_l) {
-    s << "    STAGE(s_io[a] = lk_g[site0 * W3 + e]);\n";
-  } else if (prefetch) {
+  if (prefetch) {
     // the next chunk's rows were requested during the previous chunk's output phases
     s << "    if (have_pre) { STAGE(s_io[a] = pre[k]); } else { STAGE(s_io[a] = lk_g[site0 * W3 + e]); }\n";
   } else {
@@ -339,7 +337,16 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       << "    if (full && !single_fail) {\n"
       << body
       << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
-      << "    }\n"
+      << "    }\n";
+    if (prefetch)
+      s << "    have_pre = ch + 1 < c_hi;\n"
+        << "    if (have_pre) {\n"
+        << "      const long site1 = site0 + BT;\n"
+        << "      const int nel1 = (n_sites - site1 < BT ? (int)(n_sites - site1) : BT) * W3;\n"
+        << "      { int e = tid;\n"
+        << "        _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { pre[k] = e < nel1 ? lk_g[site1 * W3 + e] : 0.0; e += BT; } }\n"
+        << "    }\n";
+    s
       << "    LDS_BARRIER();\n"
       << "    STAGE(post_g[site0 * W3 + e] = s_io[a]);\n"
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
