@@ -32,6 +32,8 @@ WORKLOADS = {  # name -> (BASELINE.json config number, default sites per GPU)
     "ped10": (2, 10_000_000),
     "ped15": (4, 131_072),
 }
+CONFIG_OF = {"ped5": "configs[1]", "ped10": "configs[2] (1 GPU) / configs[3] (8 GPUs), the configuration the north-star target "
+                                             "of >= 10 M sites/s is quoted on", "ped15": "configs[4]"}
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TOPS = 39.3   # fp64 vector instructions-lanes/s: 78.6 TFLOP/s (FMA = 2 flops) / 2
 
@@ -49,6 +51,7 @@ def parse():
     ap.add_argument("--engine", default="enum", choices=["enum", "elim"],
                     help="engine of the headline number (enum = the 3^N enumeration the metric is defined on)")
     ap.add_argument("--no-elim", action="store_true", help="skip the side measurement of the elimination engine")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the short run of BASELINE configs[1] (ped5)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the rank logic)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
@@ -120,6 +123,46 @@ def cpu_baseline(ped, cfg, seconds, n):
             "sample": "%d seeded %s sites (same generator as the GPU batch) on %d pthreads in %.1f s; "
                       "1 thread: %d sites in %.1f s" % (na, ped_name(ped), cores, ta, n1, t1),
             "one_core_sites_per_s": n1 / t1, "configs_per_s_per_core": n1 / t1 * 3 ** n}
+
+
+def side_config(fs, torch, dev, stream, workload, steps, warmup):
+    """A second BASELINE configuration measured in the same process (same contract: resident
+    inputs, HIP events on the launch stream), reported as a sub-object of the headline line."""
+    cfg, S = WORKLOADS[workload]
+    ped = fs.synthetic_pedigree(workload)
+    n = ped.n
+    mo, fa = ped.relations()
+    ctx = fs.Context(fs.make_model(ped), device=dev.index or 0)
+    lk, flags = fs.synth.gen_batch_torch(mo.tolist(), fa.tolist(), S, cfg, device=dev)
+    post, single = torch.empty_like(lk), torch.empty_like(lk)
+    status = torch.empty(S, dtype=torch.uint8, device=dev)
+
+    def step():
+        ctx.bn_batch_device(S, lk.data_ptr(), flags.data_ptr(), post.data_ptr(), single.data_ptr(), status.data_ptr(),
+                            stream.cuda_stream)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms = sum(s.elapsed_time(e) for s, e in ev) / steps
+    ok = int((status != 0).sum().item()) == 0 and float((post.sum(dim=2) - 1).abs().max().item()) < 1e-9
+    bps = 72 * n + 2
+    plan = ctx.plan()
+    ctx.close()
+    return {"workload": "BASELINE.json %s: %s, %d seeded synthetic sites, %d-member pedigree (3^%d = %d configs/site)"
+                        % (CONFIG_OF[workload], workload, S, n, n, 3 ** n),
+            "value": S * steps / elapsed, "unit": "sites/s", "ms_per_step": elapsed / steps * 1e3, "outputs_valid": ok,
+            "roofline": {"bound": "hbm", "achieved": S * bps / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": S * bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": k_ms, "bytes_per_site": bps,
+                         "kernel": "famseq_enum_lane" if plan["enum_lane_code_object"] else "bn_enum_kernel<%d>" % plan["L"]}}
 
 
 def ped_name(ped):
@@ -259,8 +302,9 @@ def main():
             "value": value, "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d seeded synthetic sites per GPU, %d-member pedigree (3^%d = %d configs/site), "
-                                   "-method 1 BN posterior, all sites full enumeration" % (a.workload, S, n, n, 3 ** n),
+            "config": {"workload": "BASELINE.json %s: %s — %d seeded synthetic sites per GPU, %d-member pedigree "
+                                   "(3^%d = %d configs/site), -method 1 BN posterior, every site takes the full enumeration"
+                                   % (CONFIG_OF[a.workload], a.workload, S, n, n, 3 ** n),
                        "sites_per_gpu": S, "global_sites": total_sites, "parallelism": "sites sharded x%d, no collective" % world,
                        "engine": a.engine,
                        "team_kernel_plan": {k: plan[k] for k in ("L", "A", "J", "team_lanes", "teams_per_block", "block_threads",
@@ -277,6 +321,8 @@ def main():
         }
         if elim_out is not None:
             out["elim_engine"] = elim_out
+        if a.workload == "ped10" and world == 1 and a.engine == "enum" and not a.no_side_configs:
+            out["configs_1_ped5"] = side_config(fs, torch, dev, stream, "ped5", a.steps, a.warmup)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ped, cfg, a.cpu_seconds, n)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
