@@ -108,6 +108,7 @@ class Gen {
 
   std::string body() {
     compute_deps();
+    choose_superleaf();
     const int no = (int)s_.outer.size(), row_len = (3 * s_.N) | 1;
     l_in_lds_ = 6 * no <= row_len;
     o_ << "      // outer (looped) members:";
@@ -210,6 +211,33 @@ class Gen {
         if (in[l]) dep_[k].push_back(l);
     }
   }
+  // Super-leaf: the deepest t levels are walked together.  Their factors are multiplied once per
+  // outer step into a combined table W (3^t entries per combination of the upper digits they
+  // depend on), so each of the 3^t configurations below a prefix costs exactly one FMA
+  // (prefix * W into the deepest member's marginal) and the other t-1 members take one FMA per
+  // combination of their own and the shallower super-leaf digits (prefix * WQ).  No products are
+  // formed inside the block for these levels.
+  int sl_ = 1;  // t
+  void choose_superleaf() {
+    sl_ = 1;
+    for (int t = std::min(3, nu_); t >= 2; --t) {
+      const int d = (int)dep_[nu_ - t].size();
+      int doubles = pow3(t + d);
+      for (int j = 0; j + 1 < t; ++j) doubles += pow3(j + 1 + d);
+      if (doubles <= 45) {
+        sl_ = t;
+        break;
+      }
+    }
+  }
+  std::string sl_name(const char *prefix, int upto, const std::vector<int> &dig) const {  // W / WQ<j> entry
+    const int k0 = nu_ - sl_;
+    std::string n = prefix;
+    for (int k = k0; k <= upto; ++k) n += "_" + num(dig[k]);
+    for (int l : dep_[k0]) n += "_" + num(l) + "d" + num(dig[l]);
+    return n;
+  }
+
   // Q<k>[digits of dep_[k]] = sum over the configurations of levels k.. of prod w: the total
   // weight below a node, per unit of prefix.  Q<nu> = 1.
   std::string q_name(int k, const std::vector<int> &dig) const {
@@ -254,13 +282,85 @@ class Gen {
         o_ << ind << "const double " << q_name(k, dig) << " = " << e << ";\n";
       }
     }
+    if (sl_ < 2) return;
+    // super-leaf tables: running products over the t levels, per combination of the upper digits
+    const int k0 = nu_ - sl_, nd = (int)dep_[k0].size();
+    std::vector<int> dig(nu_, 0);
+    for (int code = 0; code < pow3(nd); ++code) {
+      int c = code;
+      for (int l : dep_[k0]) {
+        dig[l] = c % 3;
+        c /= 3;
+      }
+      std::function<void(int, const std::string &)> walk = [&](int k, const std::string &prod) {
+        for (int g = 0; g < 3; ++g) {
+          dig[k] = g;
+          const std::string w = w_name(k, g, dig);
+          std::string here = w;
+          if (!prod.empty()) {
+            here = sl_name(k == nu_ - 1 ? "W" : "X", k, dig);
+            o_ << ind << "const double " << here << " = " << prod << " * " << w << ";\n";
+          } else if (k == nu_ - 1) {  // t == 1 never reaches here
+            here = w;
+          }
+          if (k < nu_ - 1) {
+            o_ << ind << "const double " << sl_name(("WQ" + num(k - k0)).c_str(), k, dig) << " = " << here << " * "
+               << q_name(k + 1, dig) << ";\n";
+            walk(k + 1, here);
+          }
+        }
+      };
+      walk(k0, "");
+    }
   }
 
   // Level k of the unrolled block: one product per child prefix, one FMA into the level's own
   // marginal with the child's block sum; the deepest level forms each configuration's weight in
   // the FMA that adds it to that member's marginal.
+  void superleaf(const std::string &P, std::vector<int> &dig, const std::string &ind) {
+    const int k0 = nu_ - sl_, last = s_.unrolled[nu_ - 1];
+    // every configuration: one FMA, its joint weight formed as prefix * W
+    std::function<void(int)> leaves = [&](int k) {
+      for (int g = 0; g < 3; ++g) {
+        dig[k] = g;
+        if (k < nu_ - 1) {
+          leaves(k + 1);
+          continue;
+        }
+        o_ << ind << "b" << last << "_" << g << " = __builtin_fma(" << P << ", " << sl_name("W", nu_ - 1, dig) << ", b"
+           << last << "_" << g << ");\n";
+      }
+      if (k == nu_ - 1)
+        o_ << ind << "asm volatile(\"\" : \"+v\"(b" << last << "_0), \"+v\"(b" << last << "_1), \"+v\"(b" << last
+           << "_2), \"+v\"(" << P << "));\n";
+    };
+    leaves(k0);
+    // the shallower super-leaf members: one FMA per combination of their digits
+    for (int j = 0; j + 1 < sl_; ++j) {
+      const int p = s_.unrolled[k0 + j];
+      std::function<void(int)> bins = [&](int k) {
+        for (int g = 0; g < 3; ++g) {
+          dig[k] = g;
+          if (k < k0 + j) {
+            bins(k + 1);
+            continue;
+          }
+          o_ << ind << "b" << p << "_" << g << " = __builtin_fma(" << P << ", " << sl_name(("WQ" + num(j)).c_str(), k0 + j, dig)
+             << ", b" << p << "_" << g << ");\n";
+        }
+      };
+      bins(k0);
+      o_ << ind << "asm volatile(\"\" : \"+v\"(b" << p << "_0), \"+v\"(b" << p << "_1), \"+v\"(b" << p << "_2), \"+v\"("
+         << P << "));\n";
+    }
+  }
+
   void level(int k, const std::string &P, std::vector<int> &dig, const std::string &ind) {
     const int p = s_.unrolled[k];
+    if (sl_ >= 2 && k == nu_ - sl_) {
+      superleaf(P, dig, ind);
+      return;
+    }
     if (k == nu_ - 1) {
       for (int g = 0; g < 3; ++g)
         o_ << ind << "b" << p << "_" << g << " = __builtin_fma(" << P << ", " << w_name(k, g, dig) << ", b" << p << "_" << g
