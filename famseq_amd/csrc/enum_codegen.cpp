@@ -104,15 +104,52 @@ Shape choose_shape(const famseq_model &m, int cap) {
 
 class Gen {
  public:
-  Gen(const famseq_model &m, const Shape &s) : m_(m), s_(s), nu_((int)s.unrolled.size()) {}
+  Gen(const famseq_model &m, const Shape &s) : m_(m), s_(s), nu_((int)s.unrolled.size()), outer_(s.outer) {}
+
+  // The per-step tables are plain expressions of the loop digits, so the compiler hoists each one
+  // to the outermost loop whose digit it mentions.  Put the member whose digit feeds the most
+  // table entries outermost (among members of equal depth, parents still enclose children).
+  void order_outer_loops() {
+    const int N = s_.N;
+    std::vector<int> depth(N, 0), cost(N, 0);
+    for (int pass = 0; pass < N; ++pass)
+      for (int i = 0; i < N; ++i)
+        if (m_.mother[i] >= 0) depth[i] = std::max(depth[i], 1 + std::max(depth[m_.mother[i]], depth[m_.father[i]]));
+    std::vector<std::vector<char>> feeds(nu_, std::vector<char>(N, 0));  // outer parents of level k
+    for (int k = 0; k < nu_; ++k) {
+      const int p = s_.unrolled[k];
+      if (m_.mother[p] < 0) continue;
+      for (int par : {m_.mother[p], m_.father[p]})
+        if (s_.upos[par] < 0) feeds[k][par] = 1;
+    }
+    for (int o : outer_) {
+      bool below = false;  // does any level >= k depend on o?
+      for (int k = nu_ - 1; k >= 0; --k) {
+        const int p = s_.unrolled[k];
+        if (feeds[k][o]) {
+          int e = 3;
+          if (m_.mother[p] >= 0) e *= (s_.upos[m_.mother[p]] >= 0 ? 3 : 1) * (s_.upos[m_.father[p]] >= 0 ? 3 : 1);
+          cost[o] += e;
+          below = true;
+        }
+        if (below) cost[o] += pow3((int)dep_[k].size());                                   // Q<k>
+        if (below && sl_ >= 2 && k == nu_ - sl_) cost[o] += pow3(sl_ + (int)dep_[k].size()) * 3 / 2;  // W, WQ, X
+      }
+    }
+    std::stable_sort(outer_.begin(), outer_.end(), [&](int a, int b) {
+      if (depth[a] != depth[b]) return depth[a] < depth[b];
+      return cost[a] > cost[b];
+    });
+  }
 
   std::string body() {
     compute_deps();
     choose_superleaf();
-    const int no = (int)s_.outer.size(), row_len = (3 * s_.N) | 1;
+    order_outer_loops();
+    const int no = (int)outer_.size(), row_len = (3 * s_.N) | 1;
     l_in_lds_ = 6 * no <= row_len;
     o_ << "      // outer (looped) members:";
-    for (int p : s_.outer) o_ << " " << p;
+    for (int p : outer_) o_ << " " << p;
     o_ << " | unrolled block:";
     for (int p : s_.unrolled) o_ << " " << p;
     o_ << " (" << pow3(nu_) << " configurations per outer step)\n";
@@ -123,15 +160,15 @@ class Gen {
     for (int k = 0; k < no; ++k)
       for (int g = 0; g < 3; ++g) {
         o_ << "      row[" << 3 * k + g << "] = 0;\n";
-        if (l_in_lds_) o_ << "      row[" << 3 * no + 3 * k + g << "] = l" << s_.outer[k] << "_" << g << ";\n";
+        if (l_in_lds_) o_ << "      row[" << 3 * no + 3 * k + g << "] = l" << outer_[k] << "_" << g << ";\n";
       }
     for (int p : s_.unrolled)
       o_ << "      double b" << p << "_0 = 0, b" << p << "_1 = 0, b" << p << "_2 = 0;\n";
     o_ << "      const double P_root = 10000000.0;\n";  // family.cpp:911
     outer_level(0, "P_root", "");
     for (int k = 0; k < no; ++k)
-      o_ << "      const double b" << s_.outer[k] << "_0 = row[" << 3 * k << "], b" << s_.outer[k] << "_1 = row[" << 3 * k + 1
-         << "], b" << s_.outer[k] << "_2 = row[" << 3 * k + 2 << "];\n";
+      o_ << "      const double b" << outer_[k] << "_0 = row[" << 3 * k << "], b" << outer_[k] << "_1 = row[" << 3 * k + 1
+         << "], b" << outer_[k] << "_2 = row[" << 3 * k + 2 << "];\n";
     for (int p = 0; p < s_.N; ++p)
       o_ << "      { const double s = (b" << p << "_0 + b" << p << "_1) + b" << p << "_2; if (s <= 0) bn_fail = true;\n"
          << "        row[" << 3 * p << "] = b" << p << "_0 / s; row[" << 3 * p + 1 << "] = b" << p << "_1 / s; row["
@@ -143,6 +180,7 @@ class Gen {
   const famseq_model &m_;
   const Shape &s_;
   const int nu_;
+  std::vector<int> outer_;  // looped members, outermost first
   std::ostringstream o_;
   int uid_ = 0;
   bool l_in_lds_ = false;
@@ -165,12 +203,12 @@ class Gen {
   }
 
   void outer_level(size_t k, const std::string &P, const std::string &acc_parent) {
-    if (k == s_.outer.size()) {
+    if (k == outer_.size()) {
       block(P, acc_parent);
       return;
     }
-    const int p = s_.outer[k];
-    const int no = (int)s_.outer.size();
+    const int p = outer_[k];
+    const int no = (int)outer_.size();
     const std::string g = "g" + num(p), ind(6 + 2 * k, ' ');
     const std::string lk_g = l_in_lds_ ? "row[" + num(3 * no + 3 * (int)k) + " + " + g + "]"
                                        : "(" + g + " == 0 ? l" + num(p) + "_0 : (" + g + " == 1 ? l" + num(p) + "_1 : l" + num(p) + "_2))";
@@ -382,7 +420,7 @@ class Gen {
   }
 
   void block(const std::string &P, const std::string &acc_parent) {
-    const std::string ind(6 + 2 * s_.outer.size(), ' ');
+    const std::string ind(6 + 2 * outer_.size(), ' ');
     o_ << ind << "{\n";
     const std::string in2 = ind + "  ";
     tables(in2);
