@@ -165,6 +165,8 @@ class Gen {
     for (int p : s_.unrolled)
       o_ << "      double b" << p << "_0 = 0, b" << p << "_1 = 0, b" << p << "_2 = 0;\n";
     o_ << "      const double P_root = 10000000.0;\n";  // family.cpp:911
+    tables();
+    o_ << bucket_[0];
     outer_level(0, "P_root", "");
     for (int k = 0; k < no; ++k)
       o_ << "      const double b" << outer_[k] << "_0 = row[" << 3 * k << "], b" << outer_[k] << "_1 = row[" << 3 * k + 1
@@ -215,7 +217,8 @@ class Gen {
     o_ << ind << "for (int " << g << " = 0; " << g << " < 3; ++" << g << ") {\n"
        << ind << "  const double f" << p << " = tcf[" << t_index(p, g, -1, -1) << "] * " << lk_g << ";\n"
        << ind << "  const double P" << p << " = " << P << " * f" << p << ";\n"
-       << ind << "  double acc" << p << " = 0;\n";
+       << ind << "  double acc" << p << " = 0;\n"
+       << bucket_[k + 1];
     outer_level(k + 1, "P" + num(p), "acc" + num(p));
     o_ << ind << "  row[" << 3 * (int)k << " + " << g << "] += acc" << p << ";\n";
     if (!acc_parent.empty()) o_ << ind << "  " << acc_parent << " += acc" << p << ";\n";
@@ -285,8 +288,30 @@ class Gen {
     return n;
   }
 
-  void tables(const std::string &ind) {
+  // Table statements, bucketed by the innermost outer loop whose digit they mention
+  // (index into outer_, -1 = none): each bucket is emitted at the top of that loop's body, so a
+  // table is rebuilt only when a digit it depends on changes.
+  std::vector<std::string> bucket_;  // [outer position + 1]
+
+  int outer_pos(int member) const {
+    for (size_t k = 0; k < outer_.size(); ++k)
+      if (outer_[k] == member) return (int)k;
+    return -1;
+  }
+
+  void tables() {
+    const std::string ind = "        ";
+    bucket_.assign(outer_.size() + 1, "");
+    std::vector<int> wb(nu_, -1), qb(nu_ + 1, -1);  // bucket of level k's factor table / block sums
     for (int k = 0; k < nu_; ++k) {
+      const int p = s_.unrolled[k];
+      if (m_.mother[p] >= 0)
+        for (int par : {m_.mother[p], m_.father[p]})
+          if (s_.upos[par] < 0) wb[k] = std::max(wb[k], outer_pos(par));
+    }
+    for (int k = nu_ - 1; k >= 0; --k) qb[k] = std::max(qb[k + 1], wb[k]);
+    for (int k = 0; k < nu_; ++k) {
+      std::ostringstream o;
       const int p = s_.unrolled[k];
       const bool has = m_.mother[p] >= 0;
       const bool mu = has && s_.upos[m_.mother[p]] >= 0, fu = has && s_.upos[m_.father[p]] >= 0;
@@ -296,12 +321,14 @@ class Gen {
           if (mu) suffix += "m" + num(gm);
           if (fu) suffix += "f" + num(gf);
           for (int g = 0; g < 3; ++g)
-            o_ << ind << "const double w" << p << "_" << g << suffix << " = tcf["
-               << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * l" << p << "_" << g << ";\n";
+            o << ind << "const double w" << p << "_" << g << suffix << " = tcf["
+              << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * l" << p << "_" << g << ";\n";
         }
+      bucket_[wb[k] + 1] += o.str();
     }
     // block sums, deepest level first
     for (int k = nu_ - 1; k >= 0; --k) {
+      std::ostringstream o;
       const int nd = (int)dep_[k].size();
       std::vector<int> dig(nu_, 0);
       for (int code = 0; code < pow3(nd); ++code) {
@@ -317,11 +344,13 @@ class Gen {
           if (q == "1.0") e = e.empty() ? w : "(" + e + " + " + w + ")";
           else e = e.empty() ? "(" + w + " * " + q + ")" : "__builtin_fma(" + w + ", " + q + ", " + e + ")";
         }
-        o_ << ind << "const double " << q_name(k, dig) << " = " << e << ";\n";
+        o << ind << "const double " << q_name(k, dig) << " = " << e << ";\n";
       }
+      bucket_[qb[k] + 1] += o.str();
     }
     if (sl_ < 2) return;
     // super-leaf tables: running products over the t levels, per combination of the upper digits
+    std::ostringstream o;
     const int k0 = nu_ - sl_, nd = (int)dep_[k0].size();
     std::vector<int> dig(nu_, 0);
     for (int code = 0; code < pow3(nd); ++code) {
@@ -337,24 +366,20 @@ class Gen {
           std::string here = w;
           if (!prod.empty()) {
             here = sl_name(k == nu_ - 1 ? "W" : "X", k, dig);
-            o_ << ind << "const double " << here << " = " << prod << " * " << w << ";\n";
-          } else if (k == nu_ - 1) {  // t == 1 never reaches here
-            here = w;
+            o << ind << "const double " << here << " = " << prod << " * " << w << ";\n";
           }
           if (k < nu_ - 1) {
-            o_ << ind << "const double " << sl_name(("WQ" + num(k - k0)).c_str(), k, dig) << " = " << here << " * "
-               << q_name(k + 1, dig) << ";\n";
+            o << ind << "const double " << sl_name(("WQ" + num(k - k0)).c_str(), k, dig) << " = " << here << " * "
+              << q_name(k + 1, dig) << ";\n";
             walk(k + 1, here);
           }
         }
       };
       walk(k0, "");
     }
+    bucket_[qb[k0] + 1] += o.str();
   }
 
-  // Level k of the unrolled block: one product per child prefix, one FMA into the level's own
-  // marginal with the child's block sum; the deepest level forms each configuration's weight in
-  // the FMA that adds it to that member's marginal.
   void superleaf(const std::string &P, std::vector<int> &dig, const std::string &ind) {
     const int k0 = nu_ - sl_, last = s_.unrolled[nu_ - 1];
     // every configuration: one FMA, its joint weight formed as prefix * W
@@ -423,7 +448,6 @@ class Gen {
     const std::string ind(6 + 2 * outer_.size(), ' ');
     o_ << ind << "{\n";
     const std::string in2 = ind + "  ";
-    tables(in2);
     std::vector<int> dig(nu_, 0);
     o_ << in2 << "double Pb = " << P << ";\n";
     if (!acc_parent.empty()) o_ << in2 << acc_parent << " += Pb * " << q_name(0, dig) << ";\n";
