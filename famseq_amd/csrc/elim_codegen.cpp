@@ -255,9 +255,11 @@ int elim_block_threads(const famseq_model &m) {
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l) {
   const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1;
-  // Prefetching the next chunk costs W3 doubles of registers next to the W3 marginals; measured on
-  // MI355X it pays up to 7 members (ped5: +14 %) and spills beyond (ped10: -35 %).
-  const bool prefetch = N <= 7;
+  // Prefetching the next chunk costs W3 doubles of registers next to the W3 marginals; on MI355X it
+  // pays while it does not spill (ped5: +14 %); beyond the limits below it spills and loses.
+  int prefetch_max_n = regs_l ? 7 : 10;  // the register-resident shell already holds the row: less room
+  if (const char *e = std::getenv("FAMSEQ_PREFETCH_MAXN")) prefetch_max_n = std::atoi(e);  // tuning aid
+  const bool prefetch = N <= prefetch_max_n;
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
@@ -270,7 +272,10 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     // quotient and remainder are stepped incrementally instead of divided out per element.  The
     // loop is fully unrolled so that all W3 global loads of a lane are in flight together (a
     // rolled loop serialises W3 HBM latencies per chunk).
-    << "#define STAGE(stmt) { int e = tid, a = (tid / W3) * ROW + tid % W3, r = tid % W3; \\\n"
+    // (the empty asm makes the lane id opaque at each use: otherwise hipcc hoists the 3 x W3 staging
+    // addresses out of the chunk loop and keeps ~90 registers of them alive, spilled, kernel-wide)
+    << "#define STAGE(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
+    << "  int e = t_, a = (t_ / W3) * ROW + t_ % W3, r = t_ % W3; \\\n"
     << "  _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { if (e < nel) { stmt; } e += BT; r += BT % W3; a += (BT / W3) * ROW + BT % W3; \\\n"
     << "    if (r >= W3) { r -= W3; a += ROW - W3; } } }\n";
   if (!regs_l)
@@ -322,7 +327,8 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       if (flags_pass && m.sequenced[p])
         s << "      double big = 0; if (big < a0) big = a0; if (big < a1) big = a1; if (big < a2) big = a2;\n"
           << "      const double sum = (a0 + a1) + a2; big = big / sum; if (big < lc) full = true;\n";
-      s << "    }\n";
+      // fence: one member at a time (interleaved division sequences would spill)
+      s << "    }\n    asm volatile(\"\" ::: \"memory\");\n";
     }
   };
   if (regs_l) {

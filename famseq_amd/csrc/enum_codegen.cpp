@@ -162,6 +162,10 @@ class Gen {
         o_ << "      row[" << 3 * k + g << "] = 0;\n";
         if (l_in_lds_) o_ << "      row[" << 3 * no + 3 * k + g << "] = l" << outer_[k] << "_" << g << ";\n";
       }
+    // The unrolled members' likelihoods are needed only where their tables are rebuilt (outer loop
+    // levels); re-reading them from the site's own row in global memory there (L2 hits) frees 6
+    // registers per member for the block.
+    o_ << "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;\n";
     for (int p : s_.unrolled)
       o_ << "      double b" << p << "_0 = 0, b" << p << "_1 = 0, b" << p << "_2 = 0;\n";
     o_ << "      const double P_root = 10000000.0;\n";  // family.cpp:911
@@ -214,7 +218,8 @@ class Gen {
     const std::string g = "g" + num(p), ind(6 + 2 * k, ' ');
     const std::string lk_g = l_in_lds_ ? "row[" + num(3 * no + 3 * (int)k) + " + " + g + "]"
                                        : "(" + g + " == 0 ? l" + num(p) + "_0 : (" + g + " == 1 ? l" + num(p) + "_1 : l" + num(p) + "_2))";
-    o_ << ind << "for (int " << g << " = 0; " << g << " < 3; ++" << g << ") {\n"
+    o_ << "#pragma unroll 1\n"  // keep the walk rolled: an unrolled outer loop triples the block's live state
+       << ind << "for (int " << g << " = 0; " << g << " < 3; ++" << g << ") {\n"
        << ind << "  const double f" << p << " = tcf[" << t_index(p, g, -1, -1) << "] * " << lk_g << ";\n"
        << ind << "  const double P" << p << " = " << P << " * f" << p << ";\n"
        << ind << "  double acc" << p << " = 0;\n"
@@ -322,7 +327,7 @@ class Gen {
           if (fu) suffix += "f" + num(gf);
           for (int g = 0; g < 3; ++g)
             o << ind << "const double w" << p << "_" << g << suffix << " = tcf["
-              << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * l" << p << "_" << g << ";\n";
+              << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * lg[" << 3 * p + g << "];\n";
         }
       bucket_[wb[k] + 1] += o.str();
     }
