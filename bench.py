@@ -306,7 +306,7 @@ def main():
                                    "(3^%d = %d configs/site), -method 1 BN posterior, every site takes the full enumeration"
                                    % (CONFIG_OF[a.workload], a.workload, S, n, n, 3 ** n),
                        "sites_per_gpu": S, "global_sites": total_sites, "parallelism": "sites sharded x%d, no collective" % world,
-                       "engine": a.engine,
+                       "engine": a.engine, "lane_kernel_tiling": plan.get("enum_lane_shape"),
                        "team_kernel_plan": {k: plan[k] for k in ("L", "A", "J", "team_lanes", "teams_per_block", "block_threads",
                                                                  "lds_bytes", "blocks_per_cu")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -354,7 +354,7 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
   c->json.pop_back();
   c->json += ",\"engine\":" + std::to_string(c->engine) + ",\"elim_supported\":" +
              std::string(elim_supported(c->model, nullptr) ? "1" : "0") + ",\"elim_code_object\":\"" + c->elim.path +
-             "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + c->lane.path +
+             "\",\"enum_lane_shape\":\"" + enumgen_describe(c->model) + "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + c->lane.path +
              "\",\"enum_lane_failed\":" + std::string(c->lane_failed ? "1" : "0") + ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
              ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + "}";
   return c->json.c_str();

@@ -463,6 +463,19 @@ class Gen {
 
 }  // namespace
 
+std::string enumgen_describe(const famseq_model &m) {
+  int cap = 6;
+  if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);
+  const Shape s = choose_shape(m, cap);
+  std::string d = "looped members [";
+  for (size_t k = 0; k < s.outer.size(); ++k) d += (k ? " " : "") + num(s.outer[k]);
+  d += "], unrolled block [";
+  for (size_t k = 0; k < s.unrolled.size(); ++k) d += (k ? " " : "") + num(s.unrolled[k]);
+  int n = 1;
+  for (size_t k = 0; k < s.unrolled.size(); ++k) n *= 3;
+  return d + "] = " + num(n) + " configurations per step";
+}
+
 int enumgen_block_threads(const famseq_model &m) {
   if (const char *e = std::getenv("FAMSEQ_LANE_BT")) return std::atoi(e);  // tuning aid
   return m.n_members <= 10 ? 256 : 128;
