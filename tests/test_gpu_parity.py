@@ -254,3 +254,32 @@ def test_degenerate_pedigrees():
             ctx.close()
             assert np.array_equal(st, ref[2]) and np.array_equal(single, ref[1])
             np.testing.assert_allclose(post, ref[0], rtol=RTOL, atol=0)
+
+
+def test_non_finite_and_negative_likelihoods_follow_the_reference():
+    """Garbage in.  Branch decisions (status byte) and the single posterior are the same
+    statements as the CPU code (`s <= 0` is false for NaN, `big < lc` is false for NaN, ...), so
+    they must agree bit for bit even for NaN / Inf / negative likelihoods.  The BN posterior is
+    compared only where the inputs are finite: with Inf or NaN among the factors, which marginals
+    turn NaN depends on the order of the products (inf * 0), which the device re-orders by design."""
+    c = BY["bn_synth:quad"]
+    rng = np.random.RandomState(3)
+    lk = np.tile(c.lk[:1], (48, 1, 1)).copy()
+    lk[:, 3] = 10.0 ** (-rng.randint(0, 120, size=(48, 3)) / 10.0)  # soft child: full enumeration unless broken below
+    bad = [np.nan, np.inf, -np.inf, -1.0, 0.0, 1e300]
+    for s in range(48):
+        i, g = rng.randint(0, 4), rng.randint(0, 3)
+        lk[s, i, g] = bad[s % 6]
+    finite_in = np.all(np.isfinite(lk), axis=(1, 2)) & np.all(lk >= 0, axis=(1, 2))
+    flags = (np.arange(48) % 4).astype(np.uint8)
+    ref = oracle.OracleModel(c.ids, c.mids, c.fids, c.genders, c.sequenced).bn_batch(lk, flags)
+    for opt in (dict(enum_impl=0), dict(enum_impl=1), dict(engine=fs.ENGINE_ELIM)):
+        ctx = fs.Context(fs.make_model(c.pedigree()), **opt)
+        post, single, st = ctx.bn_batch(lk, flags)
+        ctx.close()
+        assert np.array_equal(st, ref[2]), opt
+        assert np.array_equal(single, ref[1], equal_nan=True), opt
+        ok = finite_in & ((st & 3) == 0)
+        assert ok.sum() >= 10
+        np.testing.assert_allclose(post[ok], ref[0][ok], rtol=RTOL, atol=0, err_msg=str(opt))
+        assert np.all(np.isnan(post[(st & 3) != 0]))
