@@ -268,16 +268,50 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     // every barrier would wait for this wave's global stores to reach memory; nothing here hands
     // global data between lanes, so only the LDS counter has to be zero.
     << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
-    // element e = tid + k*BT of the chunk lives at LDS index a = (e / W3) * ROW + e % W3; the
-    // quotient and remainder are stepped incrementally instead of divided out per element.  The
-    // loop is fully unrolled so that all W3 global loads of a lane are in flight together (a
-    // rolled loop serialises W3 HBM latencies per chunk).
-    // (the empty asm makes the lane id opaque at each use: otherwise hipcc hoists the 3 x W3 staging
-    // addresses out of the chunk loop and keeps ~90 registers of them alive, spilled, kernel-wide)
-    << "#define STAGE(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
+    // Staging between global memory and the padded LDS rows.  Element e of the chunk (e = site-in-
+    // chunk * W3 + column) lives at LDS index a = (e / W3) * ROW + e % W3.
+    // Whole chunks (all but the last of a launch) take a branch-free, fully unrolled walk: quotient
+    // and remainder are stepped incrementally, and with no per-element predicate hipcc issues all of
+    // a lane's global accesses back to back (behind `if (e < nel)` it emitted load, s_waitcnt
+    // vmcnt(0), ds_write per element: W3 serialised HBM round trips per chunk).  The empty asm makes
+    // the lane id opaque at each use: otherwise hipcc hoists the staging addresses out of the chunk
+    // loop and keeps ~90 registers of them alive, spilled, kernel-wide.
+    //   WALK16: lane t handles the PAIRS 2t, 2t + 2 BT, ... (16 B per lane on the global side: at the
+    //           2 waves per SIMD these kernels run at, the bare skeleton moves 0.63 of the HBM peak
+    //           with 16-B accesses and 0.45 with 8-B ones — tools/io_ceiling.hip).  A chunk starts at
+    //           a multiple of BT * W3 * 8 bytes, so pairs are 16-B aligned whenever the array base is
+    //           (checked once per launch: v16).  a1 is the pair's second element, possibly in the
+    //           next row.  With W3 odd the last step covers the lower half of the lanes only.
+    //   WALK8 : lane t handles elements t, t + BT, ... (arrays that are only 8-B aligned)
+    //   TAIL  : the partial last chunk, a plain predicated loop
+    << "typedef double v2d __attribute__((ext_vector_type(2)));\n"
+    << "#define K2 ((W3 + 1) / 2)\n"
+    << "#define WALK8(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
     << "  int e = t_, a = (t_ / W3) * ROW + t_ % W3, r = t_ % W3; \\\n"
-    << "  _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { if (e < nel) { stmt; } e += BT; r += BT % W3; a += (BT / W3) * ROW + BT % W3; \\\n"
-    << "    if (r >= W3) { r -= W3; a += ROW - W3; } } }\n";
+    << "  _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { { stmt; } e += BT; r += BT % W3; a += (BT / W3) * ROW + BT % W3; \\\n"
+    << "    if (r >= W3) { r -= W3; a += ROW - W3; } } }\n"
+    << "#define WALK16(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
+    << "  int e = 2 * t_, a = (e / W3) * ROW + e % W3, r = e % W3; \\\n"
+    << "  _Pragma(\"unroll\") for (int k = 0; k < K2; ++k) { if (k < W3 / 2 || t_ < BT / 2) { \\\n"
+    << "      const int a1 = r + 1 < W3 ? a + 1 : a + 1 + ROW - W3; stmt; } \\\n"
+    << "    e += 2 * BT; r += (2 * BT) % W3; a += ((2 * BT) / W3) * ROW + (2 * BT) % W3; \\\n"
+    << "    if (r >= W3) { r -= W3; a += ROW - W3; } } }\n"
+    << "#define TAIL(stmt) { for (int e = tid; e < nel; e += BT) { const int a = (e / W3) * ROW + e % W3; stmt; } }\n"
+    // s_io <- G[site0 * W3 ...];  G[site0 * W3 ...] <- s_io;  pre <- next (whole) chunk;  s_io <- pre
+    << "#define STAGE_IN(G) { const double *g_ = (G) + site0 * W3; \\\n"
+    << "  if (!whole) { TAIL(s_io[a] = g_[e]) } \\\n"
+    << "  else if (v16) { WALK16(const v2d v_ = *(const v2d *)(g_ + e); s_io[a] = v_.x; s_io[a1] = v_.y) } \\\n"
+    << "  else { WALK8(s_io[a] = g_[e]) } }\n"
+    << "#define STAGE_OUT(G) { double *g_ = (G) + site0 * W3; \\\n"
+    << "  if (!whole) { TAIL(g_[e] = s_io[a]) } \\\n"
+    << "  else if (v16) { WALK16(v2d v_; v_.x = s_io[a]; v_.y = s_io[a1]; *(v2d *)(g_ + e) = v_) } \\\n"
+    << "  else { WALK8(g_[e] = s_io[a]) } }\n"
+    << "#define PREFETCH(G) { const double *g_ = (G) + (site0 + BT) * W3; \\\n"
+    << "  if (v16) { WALK16(pre[k] = *(const v2d *)(g_ + e); (void)a1) } \\\n"
+    << "  else { WALK8(((double *)pre)[k] = g_[e]) } }\n"
+    << "#define STAGE_PRE() { \\\n"
+    << "  if (v16) { WALK16(s_io[a] = pre[k].x; s_io[a1] = pre[k].y) } \\\n"
+    << "  else { WALK8(s_io[a] = ((double *)pre)[k]) } }\n";
   if (!regs_l)
     for (int p = 0; p < N; ++p)
       for (int gt = 0; gt < 3; ++gt) s << "#define l" << p << "_" << gt << " lrow[" << 3 * p + gt << "]\n";
@@ -294,19 +328,24 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  const long c_lo = (long)blockIdx.x * per_wg, c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;\n"
     << "  const double kNaN = __builtin_nan(\"\");\n"
     << "  double *row = s_io + tid * ROW;\n"
-    << "  const volatile double *lrow = row;  // (regs_l = false) forces a fresh LDS read per use\n"
-    << "  double pre[W3];  // (prefetch) this lane's share of the NEXT chunk, loaded ahead\n"
+    // (regs_l = false) volatile forces a fresh LDS read per use.  The address space is spelled out:
+    // hipcc does not infer it for volatile accesses and would emit flat_load instead of ds_read.
+    << "  typedef const volatile __attribute__((address_space(3))) double lds_cvd;\n"
+    << "  lds_cvd *lrow = (lds_cvd *)row;\n"
+    << "  v2d pre[K2];  // (prefetch) this lane's share of the NEXT chunk, loaded ahead\n"
+    << "  const bool v16 = (((unsigned long)lk_g | (unsigned long)post_g | (unsigned long)single_g) & 15) == 0;\n"
     << "  bool have_pre = false;\n"
     << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
     << "    const long site0 = ch * BT;\n"
     << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
     << "    const int nel = ns * W3;\n"
+    << "    const bool whole = ns == BT;\n"
     << "    LDS_BARRIER();\n";
   if (prefetch) {
     // the next chunk's rows were requested during the previous chunk's output phases
-    s << "    if (have_pre) { STAGE(s_io[a] = pre[k]); } else { STAGE(s_io[a] = lk_g[site0 * W3 + e]); }\n";
+    s << "    if (have_pre) { STAGE_PRE(); } else { STAGE_IN(lk_g); }\n";
   } else {
-    s << "    STAGE(s_io[a] = lk_g[site0 * W3 + e]);\n";
+    s << "    STAGE_IN(lk_g);\n";
   }
   s << "    LDS_BARRIER();\n"
     << "    const int fl = (tid < ns && flags_g) ? (flags_g[site0 + tid] & 3) : 0;\n"
@@ -338,23 +377,18 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     single_pass(true, true);
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << "    LDS_BARRIER();\n"
-      << "    if (single_g) { STAGE(single_g[site0 * W3 + e] = s_io[a]); }\n"
+      << "    if (single_g) { STAGE_OUT(single_g); }\n"
       << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n"
       << "    if (full && !single_fail) {\n"
       << body
       << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << "    }\n";
     if (prefetch)
-      s << "    have_pre = ch + 1 < c_hi;\n"
-        << "    if (have_pre) {\n"
-        << "      const long site1 = site0 + BT;\n"
-        << "      const int nel1 = (n_sites - site1 < BT ? (int)(n_sites - site1) : BT) * W3;\n"
-        << "      { int e = tid;\n"
-        << "        _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { pre[k] = e < nel1 ? lk_g[site1 * W3 + e] : 0.0; e += BT; } }\n"
-        << "    }\n";
+      s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
+        << "    if (have_pre) { PREFETCH(lk_g); }\n";
     s
       << "    LDS_BARRIER();\n"
-      << "    STAGE(post_g[site0 * W3 + e] = s_io[a]);\n"
+      << "    STAGE_OUT(post_g);\n"
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
       << "  }\n}\n";
   } else {
@@ -369,23 +403,18 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     if (prefetch)
       // software prefetch: issue the next chunk's loads now; they stay in flight while this
       // chunk's two output phases run (the barriers below do not wait for vmcnt)
-      s << "    have_pre = ch + 1 < c_hi;\n"
-      << "    if (have_pre) {\n"
-      << "      const long site1 = site0 + BT;\n"
-      << "      const int nel1 = (n_sites - site1 < BT ? (int)(n_sites - site1) : BT) * W3;\n"
-      << "      { int e = tid;\n"
-      << "        _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { pre[k] = e < nel1 ? lk_g[site1 * W3 + e] : 0.0; e += BT; } }\n"
-      << "    }\n";
+      s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
+      << "    if (have_pre) { PREFETCH(lk_g); }\n";
     single_pass(false, true);  // now the single posterior may take the row over
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << "    LDS_BARRIER();\n"
-      << "    if (single_g) { STAGE(single_g[site0 * W3 + e] = s_io[a]); }\n"
+      << "    if (single_g) { STAGE_OUT(single_g); }\n"
       << "    LDS_BARRIER();  // single rows are stored; sites that ran the full computation overwrite theirs\n"
       << "    if (full && !single_fail) {\n"
       << "#pragma unroll\n      for (int k = 0; k < W3; ++k) row[k] = bn_fail ? kNaN : q[k];\n"
       << "    }\n"
       << "    LDS_BARRIER();\n"
-      << "    STAGE(post_g[site0 * W3 + e] = s_io[a]);\n"
+      << "    STAGE_OUT(post_g);\n"
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
       << "  }\n}\n";
   }
