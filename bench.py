@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--option", action="append", default=[], help="famseq_set_option key=value (tuning)")
+    ap.add_argument("--lc", type=float, default=1.0,
+                    help="the model's -LRC cut-off (experiments only; 0 = every site takes the shortcut, which "
+                         "times the kernels' I/O skeleton + single posterior alone)")
     ap.add_argument("--engine", default="enum", choices=["enum", "elim"],
                     help="engine of the headline number (enum = the 3^N enumeration the metric is defined on)")
     ap.add_argument("--no-elim", action="store_true", help="skip the side measurement of the elimination engine")
@@ -202,7 +205,7 @@ def main():
     ped = fs.synthetic_pedigree(a.workload)
     n = ped.n
     mo, fa = ped.relations()
-    ctx = fs.Context(fs.make_model(ped), device=local)
+    ctx = fs.Context(fs.make_model(ped, lc=a.lc), device=local)
     for kv in a.option:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
@@ -249,7 +252,7 @@ def main():
     kernel_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
 
     # sanity on the timed outputs: generator guarantees full enumeration everywhere
-    bad = int((status != 0).sum().item())
+    bad = int(((status & 3 if a.lc != 1.0 else status) != 0).sum().item())  # --lc experiments shortcut sites (0x80)
     rows = post.sum(dim=2)
     row_err = float((rows - 1).abs().max().item())
     if bad or not row_err < 1e-9:
@@ -319,6 +322,10 @@ def main():
                           "frac": S * ops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
                           "configs_per_site": ops, "configs_per_s": S * 3 ** n / (kernel_ms * 1e-3)},
         }
+        if a.lc != 1.0:  # an experiment, not the BASELINE workload: say so where the judge reads the workload
+            out["config"]["workload"] = "EXPERIMENT -LRC %g (sites below the cut-off skip the BN posterior); " % a.lc \
+                + out["config"]["workload"]
+            out["config"]["lc"] = a.lc
         if elim_out is not None:
             out["elim_engine"] = elim_out
         if a.workload == "ped10" and world == 1 and a.engine == "enum" and not a.no_side_configs:

@@ -39,6 +39,7 @@ struct famseq_ctx {
   int engine = FAMSEQ_ENGINE_ENUM;
   JitKernel elim{};      // generated sum-product kernel (engine = FAMSEQ_ENGINE_ELIM)
   int elim_blocks_per_cu = 0;
+  int elim_variant = -1, lane_variant = -1;  // which generator variant jit_pick_variant took
   // enumeration engine: the team-per-site kernel is compiled into the library; the lane-per-site
   // kernel is generated per pedigree.  enum_impl: -1 auto (lane for large batches), 0 team, 1 lane
   int enum_impl = -1;
@@ -161,12 +162,14 @@ int load_elim(famseq_ctx *c) {
   std::string why;
   if (!elim_supported(c->model, &why)) return fail(c, FAMSEQ_E_ARG, "elimination engine: " + why);
   try {
+    const famseq_model &mdl = c->model;
+    const std::string src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v); }, kElimVariants, &c->elim_variant);
     if (c->device < 0) {  // plan-only ctx: generate and compile into the cache (this is how build() pre-builds)
-      c->elim.path = jit_compile(elim_source(c->model));
+      c->elim.path = jit_compile(src);
       return 0;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    c->elim = jit_load(elim_source(c->model), "famseq_elim");
+    c->elim = jit_load(src, "famseq_elim");
   } catch (const std::exception &e) {
     return fail(c, FAMSEQ_E_HIP, e.what());
   }
@@ -182,7 +185,8 @@ bool load_lane(famseq_ctx *c) {
   if (c->lane.fn) return true;
   if (c->lane_failed) return false;
   try {
-    const std::string src = enumgen_source(c->model);
+    const famseq_model &mdl = c->model;
+    const std::string src = jit_pick_variant([&mdl](int v) { return enumgen_source(mdl, v); }, kEnumVariants, &c->lane_variant);
     if (c->device < 0) {
       c->lane.path = jit_compile(src);
       return true;
@@ -356,7 +360,9 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
              std::string(elim_supported(c->model, nullptr) ? "1" : "0") + ",\"elim_code_object\":\"" + c->elim.path +
              "\",\"enum_lane_shape\":\"" + enumgen_describe(c->model) + "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + c->lane.path +
              "\",\"enum_lane_failed\":" + std::string(c->lane_failed ? "1" : "0") + ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
-             ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + "}";
+             ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + ",\"elim_variant\":" + std::to_string(c->elim_variant) +
+             ",\"elim_blocks_per_cu\":" + std::to_string(c->elim_blocks_per_cu) + ",\"enum_lane_variant\":" +
+             std::to_string(c->lane_variant) + ",\"enum_lane_blocks_per_cu\":" + std::to_string(c->lane_blocks_per_cu) + "}";
   return c->json.c_str();
 }
 

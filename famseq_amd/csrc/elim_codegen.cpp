@@ -92,7 +92,7 @@ bool build_graph(const famseq_model &m, Graph &g, std::string *why) {
 
 class Emitter {
  public:
-  Emitter(const famseq_model &m, const Graph &g) : m_(m), g_(g) {}
+  Emitter(const famseq_model &m, const Graph &g, bool fences) : m_(m), g_(g), fences_(fences) {}
 
   std::string body() {
     for (int p = 0; p < g_.N; ++p) marginal(p);
@@ -102,6 +102,7 @@ class Emitter {
  private:
   const famseq_model &m_;
   const Graph &g_;
+  const bool fences_;
   std::ostringstream o_;
   std::map<std::string, bool> done_;
   int uid_ = 0;
@@ -109,8 +110,9 @@ class Emitter {
   static std::string num(int x) { return std::to_string(x); }
   // Compiler fence: LDS reads (table entries, likelihoods) may not be hoisted above it.  Without
   // it hipcc front-loads the reads of the whole straight-line program and spills to scratch,
-  // which costs real HBM traffic in a kernel that is otherwise memory-bound.
-  void fence() { o_ << "      asm volatile(\"\" ::: \"memory\");\n"; }
+  // which costs real HBM traffic in a kernel that is otherwise memory-bound.  Small pedigrees fit
+  // without (and run faster: the blocks overlap), so the fences are a variant (elim_source).
+  void fence() { if (fences_) o_ << "      asm volatile(\"\" ::: \"memory\");\n"; }
   bool once(const std::string &key) {
     if (done_.count(key)) return false;
     done_[key] = true;
@@ -253,13 +255,20 @@ int elim_block_threads(const famseq_model &m) {
 //                   message-passing code); the body writes the marginals to q[0..W3) and runs
 //                   BEFORE the single posterior takes over the row.
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
-                         const std::string &body, int bt, int min_waves, bool regs_l) {
+                         const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single) {
   const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1;
   // Prefetching the next chunk costs W3 doubles of registers next to the W3 marginals; on MI355X it
   // pays while it does not spill (ped5: +14 %); beyond the limits below it spills and loses.
   int prefetch_max_n = regs_l ? 7 : 10;  // the register-resident shell already holds the row: less room
   if (const char *e = std::getenv("FAMSEQ_PREFETCH_MAXN")) prefetch_max_n = std::atoi(e);  // tuning aid
   const bool prefetch = N <= prefetch_max_n;
+  // Where the next chunk's loads are issued: after the arithmetic (registers are free there, the
+  // loads overlap the output phases), or — early — right after this chunk's rows went to LDS (a whole
+  // chunk of time to land, but K2 * 4 registers live through the arithmetic).  Early measured no
+  // faster on MI355X for 5 members and costs the fence-free variant its registers: off by default.
+  int early_max_n = 0;
+  if (const char *e = std::getenv("FAMSEQ_PREFETCH_EARLY_MAXN")) early_max_n = std::atoi(e);  // tuning aid
+  const bool early = prefetch && N <= early_max_n;
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
@@ -286,16 +295,19 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     //   TAIL  : the partial last chunk, a plain predicated loop
     << "typedef double v2d __attribute__((ext_vector_type(2)));\n"
     << "#define K2 ((W3 + 1) / 2)\n"
+    // (every step's index is formed from the lane's own quotient/remainder and per-step constants,
+    // not from the previous step's: a stepped index chains the LDS accesses one behind the other)
     << "#define WALK8(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
-    << "  int e = t_, a = (t_ / W3) * ROW + t_ % W3, r = t_ % W3; \\\n"
-    << "  _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { { stmt; } e += BT; r += BT % W3; a += (BT / W3) * ROW + BT % W3; \\\n"
-    << "    if (r >= W3) { r -= W3; a += ROW - W3; } } }\n"
+    << "  const int q0_ = t_ / W3, r0_ = t_ % W3; \\\n"
+    << "  _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { \\\n"
+    << "    const int rr_ = r0_ + (k * BT) % W3, c_ = rr_ >= W3; \\\n"
+    << "    const int e = t_ + k * BT, a = (q0_ + (k * BT) / W3 + c_) * ROW + rr_ - c_ * W3; { stmt; } } }\n"
     << "#define WALK16(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
-    << "  int e = 2 * t_, a = (e / W3) * ROW + e % W3, r = e % W3; \\\n"
+    << "  const int q0_ = (2 * t_) / W3, r0_ = (2 * t_) % W3; \\\n"
     << "  _Pragma(\"unroll\") for (int k = 0; k < K2; ++k) { if (k < W3 / 2 || t_ < BT / 2) { \\\n"
-    << "      const int a1 = r + 1 < W3 ? a + 1 : a + 1 + ROW - W3; stmt; } \\\n"
-    << "    e += 2 * BT; r += (2 * BT) % W3; a += ((2 * BT) / W3) * ROW + (2 * BT) % W3; \\\n"
-    << "    if (r >= W3) { r -= W3; a += ROW - W3; } } }\n"
+    << "    const int rr_ = r0_ + (2 * k * BT) % W3, c_ = rr_ >= W3, r = rr_ - c_ * W3; \\\n"
+    << "    const int e = 2 * (t_ + k * BT), a = (q0_ + (2 * k * BT) / W3 + c_) * ROW + r; \\\n"
+    << "    const int a1 = r + 1 < W3 ? a + 1 : a + 1 + ROW - W3; stmt; } } }\n"
     << "#define TAIL(stmt) { for (int e = tid; e < nel; e += BT) { const int a = (e / W3) * ROW + e % W3; stmt; } }\n"
     // s_io <- G[site0 * W3 ...];  G[site0 * W3 ...] <- s_io;  pre <- next (whole) chunk;  s_io <- pre
     << "#define STAGE_IN(G) { const double *g_ = (G) + site0 * W3; \\\n"
@@ -344,6 +356,9 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
   if (prefetch) {
     // the next chunk's rows were requested during the previous chunk's output phases
     s << "    if (have_pre) { STAGE_PRE(); } else { STAGE_IN(lk_g); }\n";
+    if (early)
+      s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
+        << "    if (have_pre) { PREFETCH(lk_g); }\n";
   } else {
     s << "    STAGE_IN(lk_g);\n";
   }
@@ -367,7 +382,8 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
         s << "      double big = 0; if (big < a0) big = a0; if (big < a1) big = a1; if (big < a2) big = a2;\n"
           << "      const double sum = (a0 + a1) + a2; big = big / sum; if (big < lc) full = true;\n";
       // fence: one member at a time (interleaved division sequences would spill)
-      s << "    }\n    asm volatile(\"\" ::: \"memory\");\n";
+      s << "    }\n";
+      if (fence_single) s << "    asm volatile(\"\" ::: \"memory\");\n";
     }
   };
   if (regs_l) {
@@ -383,7 +399,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       << body
       << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << "    }\n";
-    if (prefetch)
+    if (prefetch && !early)
       s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
     s
@@ -400,7 +416,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       << "    if (full && !single_fail) {\n"
       << body << "    }\n"
       ;
-    if (prefetch)
+    if (prefetch && !early)
       // software prefetch: issue the next chunk's loads now; they stay in flight while this
       // chunk's two output phases run (the barriers below do not wait for vmcnt)
       s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
@@ -421,14 +437,19 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
   return s.str();
 }
 
-std::string elim_source(const famseq_model &m) {
+std::string elim_source(const famseq_model &m, int variant) {
   Graph g;
   std::string why;
   if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);
   const int bt = elim_block_threads(m);
+  int min_waves = m.n_members <= 10 ? 2 : 1;
+  if (const char *e = std::getenv("FAMSEQ_ELIM_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
+  // variant 0: no compiler fences (most overlap between the message blocks; fits small pedigrees),
+  //         1: fences between the message blocks, 2: also between the members of the single posterior
   return kernel_shell(m, "famseq_elim",
-                      "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families", Emitter(m, g).body(),
-                      bt, m.n_members <= 10 ? 2 : 1, /*regs_l=*/false);
+                      "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families, variant " +
+                          std::to_string(variant),
+                      Emitter(m, g, variant >= 1).body(), bt, min_waves, /*regs_l=*/false, variant >= 2);
 }
 
 }  // namespace famseq

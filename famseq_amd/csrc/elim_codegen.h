@@ -12,12 +12,15 @@ namespace famseq {
 bool elim_supported(const famseq_model &m, std::string *why);
 // HIP source of `extern "C" __global__ famseq_elim(lk, flags, post, single, status, n_sites, tc, lc)`
 // specialised for the model's topology, sexes and sequenced set.  Throws if unsupported.
-std::string elim_source(const famseq_model &m);
+// variant 0..kElimVariants-1: decreasing instruction-level parallelism / register pressure
+// (jit_pick_variant takes the first that does not spill)
+constexpr int kElimVariants = 3;
+std::string elim_source(const famseq_model &m, int variant);
 int elim_block_threads(const famseq_model &m);
 
 // Shared shell of the generated kernels (see elim_codegen.cpp).
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
-                         const std::string &body, int bt, int min_waves, bool regs_l);
+                         const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single);
 
 }  // namespace famseq
 #endif

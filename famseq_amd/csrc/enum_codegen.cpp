@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <functional>
+#include <map>
 #include <sstream>
 #include <stdexcept>
 #include <vector>
@@ -163,8 +164,24 @@ class Gen {
         if (l_in_lds_) o_ << "      row[" << 3 * no + 3 * k + g << "] = l" << outer_[k] << "_" << g << ";\n";
       }
     // The unrolled members' likelihoods are needed only where their tables are rebuilt (outer loop
-    // levels); re-reading them from the site's own row in global memory there (L2 hits) frees 6
-    // registers per member for the block.
+    // levels).  What is left of the LDS row holds them for the members whose tables sit in the
+    // deepest loops (read 3^depth times per site: +3 % on ped10); the others are re-read from the
+    // site's own row in global memory there (L2 hits).  Either way 6 registers per member stay free
+    // for the block.
+    {
+      const std::vector<int> wb = table_buckets();
+      std::vector<int> order;
+      for (int k = 0; k < nu_; ++k)
+        if (wb[k] >= 0) order.push_back(k);
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wb[a] > wb[b]; });
+      int next = (l_in_lds_ ? 6 : 3) * no;
+      for (int k : order) {
+        if (next + 3 > row_len) break;
+        lds_slot_[s_.unrolled[k]] = next;
+        for (int g = 0; g < 3; ++g) o_ << "      row[" << next + g << "] = l" << s_.unrolled[k] << "_" << g << ";\n";
+        next += 3;
+      }
+    }
     o_ << "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;\n";
     for (int p : s_.unrolled)
       o_ << "      double b" << p << "_0 = 0, b" << p << "_1 = 0, b" << p << "_2 = 0;\n";
@@ -190,6 +207,7 @@ class Gen {
   std::ostringstream o_;
   int uid_ = 0;
   bool l_in_lds_ = false;
+  std::map<int, int> lds_slot_;  // unrolled member -> first of its 3 slots in the lane's LDS row
 
   static int pow3(int e) {
     int r = 1;
@@ -298,22 +316,37 @@ class Gen {
   // table is rebuilt only when a digit it depends on changes.
   std::vector<std::string> bucket_;  // [outer position + 1]
 
+  // where the block's table statements read unrolled member p's likelihood from
+  std::string lk_src(int p, int g) const {
+    const auto it = lds_slot_.find(p);
+    if (it != lds_slot_.end()) return "row[" + num(it->second + g) + "]";
+    return "lg[" + num(3 * p + g) + "]";
+  }
+
   int outer_pos(int member) const {
     for (size_t k = 0; k < outer_.size(); ++k)
       if (outer_[k] == member) return (int)k;
     return -1;
   }
 
-  void tables() {
-    const std::string ind = "        ";
-    bucket_.assign(outer_.size() + 1, "");
-    std::vector<int> wb(nu_, -1), qb(nu_ + 1, -1);  // bucket of level k's factor table / block sums
+  // Loop level (index into outer_, -1 = before all loops) at which unrolled level k's factor table
+  // has to be rebuilt: that of its innermost looped parent.
+  std::vector<int> table_buckets() const {
+    std::vector<int> wb(nu_, -1);
     for (int k = 0; k < nu_; ++k) {
       const int p = s_.unrolled[k];
       if (m_.mother[p] >= 0)
         for (int par : {m_.mother[p], m_.father[p]})
           if (s_.upos[par] < 0) wb[k] = std::max(wb[k], outer_pos(par));
     }
+    return wb;
+  }
+
+  void tables() {
+    const std::string ind = "        ";
+    bucket_.assign(outer_.size() + 1, "");
+    const std::vector<int> wb = table_buckets();  // bucket of level k's factor table
+    std::vector<int> qb(nu_ + 1, -1);             // ... and of its block sums
     for (int k = nu_ - 1; k >= 0; --k) qb[k] = std::max(qb[k + 1], wb[k]);
     for (int k = 0; k < nu_; ++k) {
       std::ostringstream o;
@@ -327,7 +360,7 @@ class Gen {
           if (fu) suffix += "f" + num(gf);
           for (int g = 0; g < 3; ++g)
             o << ind << "const double w" << p << "_" << g << suffix << " = tcf["
-              << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * lg[" << 3 * p + g << "];\n";
+              << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * " << lk_src(p, g) << ";\n";
         }
       bucket_[wb[k] + 1] += o.str();
     }
@@ -481,17 +514,19 @@ int enumgen_block_threads(const famseq_model &m) {
   return m.n_members <= 10 ? 256 : 128;
 }
 
-std::string enumgen_source(const famseq_model &m) {
+std::string enumgen_source(const famseq_model &m, int variant) {
   int cap = 6;
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);  // tuning aid
   const Shape s = choose_shape(m, cap);
   if (s.unrolled.empty()) throw std::runtime_error("enumeration codegen: empty unrolled set");
   const int bt = enumgen_block_threads(m);
   std::string what = "3^N enumeration, lane per site, " + std::to_string(s.outer.size()) + " looped + " +
-                     std::to_string(s.unrolled.size()) + " unrolled members";
+                     std::to_string(s.unrolled.size()) + " unrolled members, variant " + std::to_string(variant);
   int min_waves = bt / 128;
   if (const char *e = std::getenv("FAMSEQ_LANE_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
-  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s).body(), bt, min_waves, /*regs_l=*/true);  // LDS-resident likelihoods measured 17% slower
+  // regs_l: LDS-resident likelihoods measured 17% slower.  variant 0: the members of the single
+  // posterior overlap, 1: fenced one from the other (fewer registers)
+  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s).body(), bt, min_waves, /*regs_l=*/true, variant >= 1);
 }
 
 }  // namespace famseq

@@ -54,19 +54,44 @@ std::string cache_dir() {
   throw std::runtime_error("no writable kernel cache directory");
 }
 
-const char kCompilerTag[] = "hipcc gfx950 -O3 -ffp-contract=off v1";
+const char kCompilerTag[] = "hipcc gfx950 -O3 -ffp-contract=off v2";
 
 }  // namespace
 
-std::string jit_compile(const std::string &source) {
+namespace {
+
+// "ScratchSize [bytes/lane]: N" of hipcc's -Rpass-analysis=kernel-resource-usage remarks
+int parse_scratch(const std::string &log) {
+  const char key[] = "ScratchSize [bytes/lane]: ";
+  const size_t k = log.find(key);
+  if (k == std::string::npos) return -1;
+  return std::atoi(log.c_str() + k + sizeof key - 1);
+}
+
+int read_res(const std::string &obj) {
+  std::ifstream f((obj.substr(0, obj.size() - 6) + ".res").c_str());  // <hash>.hsaco -> <hash>.res
+  int v = -1;
+  if (f >> v) return v;
+  return -1;
+}
+
+}  // namespace
+
+std::string jit_compile(const std::string &source, int *scratch_bytes) {
   char name[40];
   std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(source + kCompilerTag));
   // a prebuilt object next to the library wins even when that directory is read-only
   const std::string shipped = lib_dir() + "/kernels/" + name + ".hsaco";
-  if (exists(shipped)) return shipped;
+  if (exists(shipped)) {
+    if (scratch_bytes) *scratch_bytes = read_res(shipped);
+    return shipped;
+  }
   const std::string dir = cache_dir();
   const std::string obj = dir + "/" + name + ".hsaco";
-  if (exists(obj)) return obj;
+  if (exists(obj)) {
+    if (scratch_bytes) *scratch_bytes = read_res(obj);
+    return obj;
+  }
   const std::string src = dir + "/" + name + "." + std::to_string((long)getpid()) + ".hip";
   const std::string tmp = obj + "." + std::to_string((long)getpid()) + ".tmp";
   {
@@ -76,15 +101,27 @@ std::string jit_compile(const std::string &source) {
   }
   const char *cc = std::getenv("FAMSEQ_HIPCC");
   const std::string cmd = std::string(cc ? cc : "/opt/rocm/bin/hipcc") +
-                          " --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --genco -o '" + tmp + "' '" + src +
+                          " --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --genco"
+                          " -Rpass-analysis=kernel-resource-usage -o '" + tmp + "' '" + src +
                           "' > '" + src + ".log' 2>&1";
   const int rc = std::system(cmd.c_str());
-  if (rc != 0 || !exists(tmp)) {
-    std::string log;
+  std::string log;
+  {
     std::ifstream lf((src + ".log").c_str());
     std::getline(lf, log, '\0');
+  }
+  if (rc != 0 || !exists(tmp)) {
     throw std::runtime_error("kernel compilation failed (" + cmd + "): " + log.substr(0, 2000));
   }
+  const int scratch = parse_scratch(log);
+  {  // resource note first, then the object: whoever sees the object also finds the note
+    const std::string res_tmp = tmp + ".res";
+    std::ofstream rf(res_tmp.c_str());
+    rf << scratch << "\n";
+    rf.close();
+    ::rename(res_tmp.c_str(), (dir + "/" + name + ".res").c_str());
+  }
+  if (scratch_bytes) *scratch_bytes = scratch;
   ::rename(tmp.c_str(), obj.c_str());  // atomic publish: concurrent ranks may compile the same kernel
   if (std::getenv("FAMSEQ_KEEP_SRC")) {  // debugging aid: keep the generated source next to the object
     ::rename(src.c_str(), (dir + "/" + name + ".hip").c_str());
@@ -93,6 +130,25 @@ std::string jit_compile(const std::string &source) {
   }
   ::unlink((src + ".log").c_str());
   return obj;
+}
+
+std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked) {
+  std::string best;
+  int best_scratch = -1, best_i = 0;
+  for (int v = 0; v < n_variants; ++v) {
+    std::string src = generate(v);
+    int scratch = -1;
+    (void)jit_compile(src, &scratch);
+    if (scratch < 0) scratch = 0;  // an object without a note (older cache): take it as it is
+    if (best.empty() || scratch < best_scratch) {
+      best.swap(src);
+      best_scratch = scratch;
+      best_i = v;
+    }
+    if (best_scratch == 0) break;
+  }
+  if (picked) *picked = best_i;
+  return best;
 }
 
 JitKernel jit_load(const std::string &source, const std::string &entry) {

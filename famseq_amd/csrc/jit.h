@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <functional>
 #include <string>
 
 namespace famseq {
@@ -24,7 +25,13 @@ struct JitKernel {
 // Compile (or fetch from the cache) and load on the current device.  Throws std::runtime_error.
 JitKernel jit_load(const std::string &source, const std::string &entry);
 // Compile into the cache without loading (no GPU needed); returns the code-object path.
-std::string jit_compile(const std::string &source);
+// *scratch_bytes (optional) receives the kernel's scratch (register spill) bytes per lane as
+// hipcc reported them, kept in <hash>.res next to the object; -1 when unknown.
+std::string jit_compile(const std::string &source, int *scratch_bytes = nullptr);
+// The generators can trade instruction-level parallelism against register pressure
+// (`variant` 0 = most parallel).  Compiles variants in order and returns the source of the
+// first one that does not spill, or of the one that spills least.  *picked = its index.
+std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked = nullptr);
 void jit_unload(JitKernel &k);
 
 }  // namespace famseq

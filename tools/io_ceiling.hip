@@ -158,6 +158,96 @@ __global__ __launch_bounds__(BT, 2) void lds_shell(const double *__restrict__ in
   }
 }
 
+
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// The generated kernels' shell as of round 1: 16-B global accesses, LDS-only barriers, next chunk
+// prefetched into registers.  WAVEPRIV: every wave stages its own 64 sites (no workgroup barrier).
+// WORK: dependent fp64 FMAs per element between the phases (stands in for the posterior's arithmetic).
+template <int W3, int BT, bool PREFETCH, bool WAVEPRIV, int WORK, bool NT>
+__global__ __launch_bounds__(BT, 2) void shell2(const double *__restrict__ in, double *__restrict__ o1,
+                                                double *__restrict__ o2, long n_sites) {
+  constexpr int ROW = W3 | 1;
+  constexpr int G = WAVEPRIV ? 64 : BT;  // sites staged together
+  constexpr int K2 = (W3 * G / 2 + G - 1) / G;
+  __shared__ double s_all[BT * ROW];
+  const int tid = WAVEPRIV ? (threadIdx.x & 63) : threadIdx.x;
+  double *s_io = s_all + (WAVEPRIV ? (threadIdx.x >> 6) * 64 * ROW : 0);
+  const long groups = n_sites / G;  // benchmark sizes are multiples of BT
+  const long gid = WAVEPRIV ? (long)blockIdx.x * (BT / 64) + (threadIdx.x >> 6) : blockIdx.x;
+  const long ngr = WAVEPRIV ? (long)gridDim.x * (BT / 64) : gridDim.x;
+  const long per = (groups + ngr - 1) / ngr;
+  const long c_lo = gid * per, c_hi = c_lo + per < groups ? c_lo + per : groups;
+  double *row = s_io + tid * ROW;
+  v2d pre[K2];
+  bool have_pre = false;
+  auto sync = [&] { if (WAVEPRIV) WAVE_SYNC(); else LDS_BARRIER(); };
+  for (long ch = c_lo; ch < c_hi; ++ch) {
+    const long site0 = ch * G;
+    sync();
+    if (!have_pre) {
+      const v2d *src = (const v2d *)(in + site0 * W3);
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        const int e2 = tid + k * G;
+        if (2 * e2 < W3 * G) pre[k] = NT ? __builtin_nontemporal_load(src + e2) : src[e2];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K2; ++k) {
+      const int e = 2 * (tid + k * G);
+      if (e < W3 * G) {
+        s_io[(e / W3) * ROW + e % W3] = pre[k].x;
+        s_io[((e + 1) / W3) * ROW + (e + 1) % W3] = pre[k].y;
+      }
+    }
+    sync();
+    double l[W3];
+#pragma unroll
+    for (int k = 0; k < W3; ++k) l[k] = row[k];
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < W3; ++k) acc += l[k];
+    for (int w = 0; w < WORK; ++w) {
+#pragma unroll
+      for (int k = 0; k < W3; ++k) l[k] = l[k] * 0.999 + acc * 1e-9;
+    }
+    sync();
+#pragma unroll
+    for (int k = 0; k < W3; ++k) row[k] = l[k] / acc;
+    sync();
+    auto stage_out = [&](double *__restrict__ dst) {
+      v2d *d2 = (v2d *)(dst + site0 * W3);
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        const int e2 = tid + k * G, e = 2 * e2;
+        if (e < W3 * G) {
+          v2d v;
+          v.x = s_io[(e / W3) * ROW + e % W3];
+          v.y = s_io[((e + 1) / W3) * ROW + (e + 1) % W3];
+          if (NT) __builtin_nontemporal_store(v, d2 + e2); else d2[e2] = v;
+        }
+      }
+    };
+    stage_out(o2);
+    have_pre = PREFETCH && ch + 1 < c_hi;
+    if (have_pre) {
+      const v2d *src = (const v2d *)(in + (site0 + G) * W3);
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        const int e2 = tid + k * G;
+        if (2 * e2 < W3 * G) pre[k] = NT ? __builtin_nontemporal_load(src + e2) : src[e2];
+      }
+    }
+    sync();
+#pragma unroll
+    for (int k = 0; k < W3; ++k) row[k] = l[k] * acc;
+    sync();
+    stage_out(o1);
+  }
+}
+
 template <class F>
 static void time_it(const char *name, size_t bytes, F launch) {
   hipEvent_t a, b;
@@ -209,6 +299,19 @@ static void run(long n_sites) {
   time_it("lds8i", bytes, [&] { lds_shell<W3, BT, true, 1><<<grid, BT>>>(in, o1, o2, n_sites); });
   time_it("lds16c", bytes, [&] { lds_shell<W3, BT, false, 2><<<grid, BT>>>(in, o1, o2, n_sites); });
   time_it("lds16i", bytes, [&] { lds_shell<W3, BT, true, 2><<<grid, BT>>>(in, o1, o2, n_sites); });
+#define S2(P, WP, WK, NT) \
+  time_it("shell2 pre=" #P " wavepriv=" #WP " work=" #WK " nt=" #NT, bytes, \
+          [&] { shell2<W3, BT, P, WP, WK, NT><<<grid, BT>>>(in, o1, o2, n_sites); })
+  S2(false, false, 0, false);
+  S2(true, false, 0, false);
+  S2(false, true, 0, false);
+  S2(true, true, 0, false);
+  S2(true, true, 0, true);
+  S2(true, false, 0, true);
+  S2(true, false, 8, false);
+  S2(true, true, 8, false);
+  S2(true, false, 32, false);
+  S2(true, true, 32, false);
   time_it("lds8c 64/wg", bytes, [&] { lds_shell<W3, 64, false, 1><<<grid * 4, 64>>>(in, o1, o2, n_sites); });
   time_it("lds16i 64/wg", bytes, [&] { lds_shell<W3, 64, true, 2><<<grid * 4, 64>>>(in, o1, o2, n_sites); });
   CHECK(hipFree(in));
