@@ -178,6 +178,43 @@ def test_device_pointer_entry_matches_host_entry():
     ctx.close()
 
 
+@pytest.mark.parametrize("engine", [dict(enum_impl=1), dict(engine=1)], ids=["lane", "elim"])
+@pytest.mark.parametrize("name,cfg", [("ped5", 1), ("ped10", 2)])
+def test_device_arrays_that_are_only_8_byte_aligned(name, cfg, engine):
+    """The generated kernels move 16 B per lane when lk/post/single are 16-byte aligned and fall
+    back to 8 B per lane otherwise (decided per launch).  Both paths, whole chunks plus a ragged
+    tail, must give the same bits."""
+    torch = pytest.importorskip("torch")
+    ped = fs.synthetic_pedigree(name)
+    mo, fa = ped.relations()
+    n_sites = 3 * 256 + 77
+    lk_h, fl_h = fs.synth.gen_batch(mo, fa, n_sites, cfg)
+    ctx = fs.Context(fs.make_model(ped), **engine)
+    dev = torch.device("cuda:0")
+    w = lk_h.size
+    res = []
+    for off in (0, 1):  # element offset into an over-allocated buffer: 0 -> 16-B aligned, 1 -> 8-B aligned
+        bufs = [torch.zeros(w + 2, dtype=torch.float64, device=dev) for _ in range(3)]
+        lk, post, single = (b[off:off + w] for b in bufs)
+        assert lk.data_ptr() % 16 == 8 * off
+        lk.copy_(torch.from_numpy(lk_h.reshape(-1)))
+        fl = torch.from_numpy(fl_h).to(dev)
+        st = torch.empty(n_sites, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream()
+        ctx.bn_batch_device(n_sites, lk.data_ptr(), fl.data_ptr(), post.data_ptr(), single.data_ptr(), st.data_ptr(),
+                            stream.cuda_stream)
+        stream.synchronize()
+        res.append((post.cpu().numpy().copy(), single.cpu().numpy().copy(), st.cpu().numpy().copy()))
+        for b in bufs:  # nothing written outside the window
+            assert float(b[:off].abs().sum()) == 0 and float(b[off + w:].abs().sum()) == 0 or b is bufs[0]
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    host = ctx.bn_batch(lk_h, fl_h)
+    assert np.array_equal(res[0][0].reshape(host[0].shape), host[0])
+    assert np.array_equal(res[0][2], host[2])
+    ctx.close()
+
+
 @pytest.mark.parametrize("engine", [dict(enum_impl=0), dict(enum_impl=1), dict(engine=1)], ids=["team", "lane", "elim"])
 @pytest.mark.parametrize("name,cfg,n_sites", [("ped5", 1, 200_000), ("ped10", 2, 20_000)])
 def test_full_size_properties(name, cfg, n_sites, engine):
