@@ -183,8 +183,17 @@ class Gen {
       }
     }
     o_ << "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;\n";
-    for (int p : s_.unrolled)
+    joint_ = sl_ >= 2;
+    if (const char *e = std::getenv("FAMSEQ_LANE_JOINT")) joint_ = joint_ && std::atoi(e) != 0;  // tuning aid
+    for (int k = 0; k < nu_; ++k) {
+      if (joint_ && k >= nu_ - sl_) continue;
+      const int p = s_.unrolled[k];
       o_ << "      double b" << p << "_0 = 0, b" << p << "_1 = 0, b" << p << "_2 = 0;\n";
+    }
+    if (joint_) {
+      std::vector<int> dig(nu_, 0);
+      for (int c = 0; c < pow3(sl_); ++c) o_ << "      double " << s_name(c, dig) << " = 0;\n";
+    }
     o_ << "      const double P_root = 10000000.0;\n";  // family.cpp:911
     tables();
     o_ << bucket_[0];
@@ -192,6 +201,24 @@ class Gen {
     for (int k = 0; k < no; ++k)
       o_ << "      const double b" << outer_[k] << "_0 = row[" << 3 * k << "], b" << outer_[k] << "_1 = row[" << 3 * k + 1
          << "], b" << outer_[k] << "_2 = row[" << 3 * k + 2 << "];\n";
+    if (joint_) {  // the super-leaf members' marginals: sums of the joint accumulators over the other digits
+      std::vector<int> dig(nu_, 0);
+      for (int j = 0; j < sl_; ++j)
+        for (int g = 0; g < 3; ++g) {
+          std::string e;
+          for (int c = 0; c < pow3(sl_); ++c) {
+            int cc = c, mine = 0;
+            for (int t = sl_ - 1; t >= 0; --t) {
+              if (t == j) mine = cc % 3;
+              cc /= 3;
+            }
+            if (mine != g) continue;
+            const std::string n = s_name(c, dig);
+            e = e.empty() ? n : "(" + e + " + " + n + ")";
+          }
+          o_ << "      const double b" << s_.unrolled[nu_ - sl_ + j] << "_" << g << " = " << e << ";\n";
+        }
+    }
     for (int p = 0; p < s_.N; ++p)
       o_ << "      { const double s = (b" << p << "_0 + b" << p << "_1) + b" << p << "_2; if (s <= 0) bn_fail = true;\n"
          << "        row[" << 3 * p << "] = b" << p << "_0 / s; row[" << 3 * p + 1 << "] = b" << p << "_1 / s; row["
@@ -207,6 +234,7 @@ class Gen {
   std::ostringstream o_;
   int uid_ = 0;
   bool l_in_lds_ = false;
+  bool joint_ = false;  // super-leaf marginals from 3^sl joint accumulators (see superleaf())
   std::map<int, int> lds_slot_;  // unrolled member -> first of its 3 slots in the lane's LDS row
 
   static int pow3(int e) {
@@ -299,6 +327,18 @@ class Gen {
     std::string n = prefix;
     for (int k = k0; k <= upto; ++k) n += "_" + num(dig[k]);
     for (int l : dep_[k0]) n += "_" + num(l) + "d" + num(dig[l]);
+    return n;
+  }
+
+  // joint accumulator of super-leaf configuration c (most significant digit = shallowest member)
+  std::string s_name(int c, std::vector<int> &dig) const {
+    const int k0 = nu_ - sl_;
+    for (int t = sl_ - 1; t >= 0; --t) {
+      dig[k0 + t] = c % 3;
+      c /= 3;
+    }
+    std::string n = "S";
+    for (int k = k0; k < nu_; ++k) n += "_" + num(dig[k]);
     return n;
   }
 
@@ -407,8 +447,9 @@ class Gen {
             o << ind << "const double " << here << " = " << prod << " * " << w << ";\n";
           }
           if (k < nu_ - 1) {
-            o << ind << "const double " << sl_name(("WQ" + num(k - k0)).c_str(), k, dig) << " = " << here << " * "
-              << q_name(k + 1, dig) << ";\n";
+            if (!joint_)
+              o << ind << "const double " << sl_name(("WQ" + num(k - k0)).c_str(), k, dig) << " = " << here << " * "
+                << q_name(k + 1, dig) << ";\n";
             walk(k + 1, here);
           }
         }
@@ -420,6 +461,25 @@ class Gen {
 
   void superleaf(const std::string &P, std::vector<int> &dig, const std::string &ind) {
     const int k0 = nu_ - sl_, last = s_.unrolled[nu_ - 1];
+    if (joint_) {
+      // Every configuration: ONE FMA — its joint weight prefix * W is formed and added to the
+      // accumulator of its super-leaf digits.  The 3^sl accumulators run over the whole site; the
+      // marginals of all sl members are sums of them, taken once at the end (body()).  Against one
+      // set of bins per member (39 FMAs per 27 configurations at sl = 3) this is 27 per 27, and
+      // the accumulators form 3^sl independent dependency chains.
+      std::vector<std::string> trio;
+      for (int c = 0; c < pow3(sl_); ++c) {
+        const std::string a = s_name(c, dig);  // sets dig[k0..]
+        o_ << ind << a << " = __builtin_fma(" << P << ", " << sl_name("W", nu_ - 1, dig) << ", " << a << ");\n";
+        trio.push_back(a);
+        if (trio.size() == 3) {
+          o_ << ind << "asm volatile(\"\" : \"+v\"(" << trio[0] << "), \"+v\"(" << trio[1] << "), \"+v\"(" << trio[2]
+             << "), \"+v\"(" << P << "));\n";
+          trio.clear();
+        }
+      }
+      return;
+    }
     // every configuration: one FMA, its joint weight formed as prefix * W
     std::function<void(int)> leaves = [&](int k) {
       for (int g = 0; g < 3; ++g) {

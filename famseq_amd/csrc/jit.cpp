@@ -81,8 +81,9 @@ std::string jit_compile(const std::string &source, int *scratch_bytes) {
   char name[40];
   std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(source + kCompilerTag));
   // a prebuilt object next to the library wins even when that directory is read-only
+  // (an explicit $FAMSEQ_KERNEL_CACHE is taken at its word: only that directory is consulted)
   const std::string shipped = lib_dir() + "/kernels/" + name + ".hsaco";
-  if (exists(shipped)) {
+  if (!std::getenv("FAMSEQ_KERNEL_CACHE") && exists(shipped)) {
     if (scratch_bytes) *scratch_bytes = read_res(shipped);
     return shipped;
   }

@@ -3,8 +3,8 @@
 // Some engines of this library are generated as straight-line HIP for one pedigree (its
 // topology fixes every index, so all per-site state lives in registers).  The source is
 // compiled with hipcc --genco for gfx950 and cached on disk by content hash:
-//   <dir of libfamseq_hip.so>/kernels/<hash>.hsaco      (in-tree: prebuilt objects travel
-//   with the library)  or  $FAMSEQ_KERNEL_CACHE  or  /tmp/famseq_kernels_<uid>.
+//   $FAMSEQ_KERNEL_CACHE when set; otherwise <dir of libfamseq_hip.so>/kernels/<hash>.hsaco
+//   (in-tree: prebuilt objects travel with the library), then /tmp/famseq_kernels_<uid>.
 // Compiler: $FAMSEQ_HIPCC or /opt/rocm/bin/hipcc.
 #ifndef FAMSEQ_JIT_H_
 #define FAMSEQ_JIT_H_
