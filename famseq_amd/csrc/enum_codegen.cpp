@@ -60,6 +60,8 @@ Shape choose_shape(const famseq_model &m, int cap) {
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth[a] < depth[b]; });
   std::vector<char> inU(N, 0);
   int nu = 0;
+  int table_budget = 48;
+  if (const char *e = std::getenv("FAMSEQ_LANE_TABLE_BUDGET")) table_budget = std::atoi(e);  // tuning aid
   auto table_doubles = [&]() {
     int t = 0;
     for (int i = 0; i < N; ++i)
@@ -77,7 +79,7 @@ Shape choose_shape(const famseq_model &m, int cap) {
     for (int c : kids[i]) ok = ok && inU[c];
     if (!ok) continue;
     inU[i] = 1;
-    if (table_doubles() > 48) {  // register budget for the block's factor tables
+    if (table_doubles() > table_budget) {  // register budget for the block's factor tables
       inU[i] = 0;
       continue;
     }
@@ -467,16 +469,11 @@ class Gen {
       // marginals of all sl members are sums of them, taken once at the end (body()).  Against one
       // set of bins per member (39 FMAs per 27 configurations at sl = 3) this is 27 per 27, and
       // the accumulators form 3^sl independent dependency chains.
-      std::vector<std::string> trio;
+      // (No pins here: the prefix products are pinned where they are formed, which is what keeps
+      // hipcc from forming all of them up front; a pin per three FMAs cost an s_nop each, -5 %.)
       for (int c = 0; c < pow3(sl_); ++c) {
         const std::string a = s_name(c, dig);  // sets dig[k0..]
         o_ << ind << a << " = __builtin_fma(" << P << ", " << sl_name("W", nu_ - 1, dig) << ", " << a << ");\n";
-        trio.push_back(a);
-        if (trio.size() == 3) {
-          o_ << ind << "asm volatile(\"\" : \"+v\"(" << trio[0] << "), \"+v\"(" << trio[1] << "), \"+v\"(" << trio[2]
-             << "), \"+v\"(" << P << "));\n";
-          trio.clear();
-        }
       }
       return;
     }
