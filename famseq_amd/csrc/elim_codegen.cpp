@@ -92,7 +92,7 @@ bool build_graph(const famseq_model &m, Graph &g, std::string *why) {
 
 class Emitter {
  public:
-  Emitter(const famseq_model &m, const Graph &g, bool fences) : m_(m), g_(g), fences_(fences) {}
+  Emitter(const famseq_model &m, const Graph &g, int fences) : m_(m), g_(g), fences_(fences) {}
 
   std::string body() {
     for (int p = 0; p < g_.N; ++p) marginal(p);
@@ -102,7 +102,7 @@ class Emitter {
  private:
   const famseq_model &m_;
   const Graph &g_;
-  const bool fences_;
+  const int fences_;  // 0 none, 1 after every family->member message, 2 also after local factors and child sums
   std::ostringstream o_;
   std::map<std::string, bool> done_;
   int uid_ = 0;
@@ -112,7 +112,7 @@ class Emitter {
   // it hipcc front-loads the reads of the whole straight-line program and spills to scratch,
   // which costs real HBM traffic in a kernel that is otherwise memory-bound.  Small pedigrees fit
   // without (and run faster: the blocks overlap), so the fences are a variant (elim_source).
-  void fence() { if (fences_) o_ << "      asm volatile(\"\" ::: \"memory\");\n"; }
+  void fence(int level) { if (fences_ >= level) o_ << "      asm volatile(\"\" ::: \"memory\");\n"; }
   bool once(const std::string &key) {
     if (done_.count(key)) return false;
     done_[key] = true;
@@ -138,7 +138,7 @@ class Emitter {
         if (scale) e = "(10000000.0 * " + e + ")";
         o_ << "      const double " << n << "_" << g << " = " << e << ";\n";
       }
-      fence();
+      fence(2);
     }
     return n;
   }
@@ -170,7 +170,7 @@ class Emitter {
       for (int gf = 0; gf < 3; ++gf)
         o_ << "      const double " << n << "_" << gm << gf << " = __builtin_fma(" << T(c, 2, gm, gf) << ", " << x
            << "_2, __builtin_fma(" << T(c, 1, gm, gf) << ", " << x << "_1, " << T(c, 0, gm, gf) << " * " << x << "_0));\n";
-    fence();
+    fence(2);
     return n;
   }
 
@@ -215,7 +215,7 @@ class Emitter {
       }
       o_ << ";\n";
     }
-    fence();
+    fence(1);
     return n;
   }
 
@@ -445,11 +445,12 @@ std::string elim_source(const famseq_model &m, int variant) {
   int min_waves = m.n_members <= 10 ? 2 : 1;
   if (const char *e = std::getenv("FAMSEQ_ELIM_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
   // variant 0: no compiler fences (most overlap between the message blocks; fits small pedigrees),
-  //         1: fences between the message blocks, 2: also between the members of the single posterior
+  //         1: a fence after every family->member message, 2: also after local factors and child
+  //         summaries, 3: also between the members of the single posterior
   return kernel_shell(m, "famseq_elim",
                       "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families, variant " +
                           std::to_string(variant),
-                      Emitter(m, g, variant >= 1).body(), bt, min_waves, /*regs_l=*/false, variant >= 2);
+                      Emitter(m, g, variant < 2 ? variant : 2).body(), bt, min_waves, /*regs_l=*/false, variant >= 3);
 }
 
 }  // namespace famseq

@@ -14,7 +14,7 @@ bool elim_supported(const famseq_model &m, std::string *why);
 // specialised for the model's topology, sexes and sequenced set.  Throws if unsupported.
 // variant 0..kElimVariants-1: decreasing instruction-level parallelism / register pressure
 // (jit_pick_variant takes the first that does not spill)
-constexpr int kElimVariants = 3;
+constexpr int kElimVariants = 4;
 std::string elim_source(const famseq_model &m, int variant);
 int elim_block_threads(const famseq_model &m);
 

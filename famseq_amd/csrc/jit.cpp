@@ -6,6 +6,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -136,7 +137,9 @@ std::string jit_compile(const std::string &source, int *scratch_bytes) {
 std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked) {
   std::string best;
   int best_scratch = -1, best_i = 0;
-  for (int v = 0; v < n_variants; ++v) {
+  int first = 0;
+  if (const char *e = std::getenv("FAMSEQ_VARIANT_MIN")) first = std::min(std::atoi(e), n_variants - 1);  // tuning aid
+  for (int v = first; v < n_variants; ++v) {
     std::string src = generate(v);
     int scratch = -1;
     (void)jit_compile(src, &scratch);
