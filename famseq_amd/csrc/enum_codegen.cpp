@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <functional>
 #include <map>
+#include <set>
 #include <sstream>
 #include <stdexcept>
 #include <vector>
@@ -175,6 +176,7 @@ class Gen {
       std::vector<int> order;
       for (int k = 0; k < nu_; ++k)
         if (wb[k] >= 0) order.push_back(k);
+        else before_loops_.insert(s_.unrolled[k]);
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wb[a] > wb[b]; });
       int next = (l_in_lds_ ? 6 : 3) * no;
       for (int k : order) {
@@ -238,6 +240,7 @@ class Gen {
   bool l_in_lds_ = false;
   bool joint_ = false;  // super-leaf marginals from 3^sl joint accumulators (see superleaf())
   std::map<int, int> lds_slot_;  // unrolled member -> first of its 3 slots in the lane's LDS row
+  std::set<int> before_loops_;   // unrolled members whose tables are built once per site
 
   static int pow3(int e) {
     int r = 1;
@@ -362,6 +365,7 @@ class Gen {
   std::string lk_src(int p, int g) const {
     const auto it = lds_slot_.find(p);
     if (it != lds_slot_.end()) return "row[" + num(it->second + g) + "]";
+    if (before_loops_.count(p)) return "l" + num(p) + "_" + num(g);  // used once, ahead of all loops: still in registers
     return "lg[" + num(3 * p + g) + "]";
   }
 

@@ -38,3 +38,24 @@ def test_loop_pedigree_is_rejected():
     with pytest.raises(fs.FamseqError):
         ctx.set_option("engine", 7)
     ctx.close()
+
+
+def test_variant_is_the_first_that_does_not_spill(tmp_path, monkeypatch):
+    """The generators emit variants from most to least instruction-level parallelism; the JIT takes
+    the first one hipcc reports spill-free and leaves that report next to each code object.
+    (A fresh cache directory: every candidate is really compiled here.)"""
+    monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
+    picked = {}
+    for name in ("ped5", "ped10"):
+        ctx = fs.Context(fs.make_model(fs.synthetic_pedigree(name)), device=-1)
+        ctx.set_option("engine", fs.ENGINE_ELIM)
+        p = ctx.plan()
+        ctx.close()
+        picked[name] = p["elim_variant"]
+        obj = p["elim_code_object"]
+        assert obj.startswith(str(tmp_path))
+        assert int(open(obj[:-6] + ".res").read()) == 0  # the variant in use has no scratch
+    notes = sorted(int(open(os.path.join(tmp_path, f)).read()) for f in os.listdir(tmp_path) if f.endswith(".res"))
+    assert picked["ped5"] == 0                      # small pedigree: fence-free fits
+    assert picked["ped10"] >= 1 and notes[-1] > 0   # wider one: variant 0 was compiled, spilled, and was passed over
+    assert len(notes) == 1 + picked["ped10"] + 1
