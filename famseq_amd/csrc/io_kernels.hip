@@ -10,7 +10,11 @@
 //                GPP/FPP = fabs(-10*log10(p)) with +inf -> 99999 (file.cpp:696-745) and
 //                FGT = arg-max with strict '<' from -1 (family.cpp:636-665), gathered in VCF
 //                column order (get_postProb(true), family.cpp:584-596).
-// Both are one-element-per-lane streaming kernels (coalesced 8 B/lane), grid-stride.
+// Both are one-element-per-lane streaming kernels (coalesced 8 B/lane).  A workgroup walks tiles of
+// kTileSites sites; inside a tile the element index is a 16-bit number, so site / member / genotype
+// come from two multiply-shift divisions (exact for n < 2^16, divisors <= 60: the launchers check
+// 3 * members <= 60) instead of the 64-bit integer divisions a flat index over n_sites * W3 costs.
+// phred_call is bound by its two fp64 log10 per element (VALU), unpack_pl16 by HBM.
 #include <hip/hip_runtime.h>
 
 #include "io_kernels.h"
@@ -19,25 +23,37 @@ namespace famseq {
 
 namespace {
 
+constexpr int kTileSites = 128;  // 128 * 60 = 7680 elements per tile (must stay < 2^16)
+
+// n / d for n < 2^16, 1 <= d <= 60: the high word of n * (2^32 / d + 1) (error < n / 2^32 < 1 / d)
+__device__ __forceinline__ unsigned div_small(unsigned n, unsigned magic) { return __umulhi(n, magic); }
+__host__ __device__ constexpr unsigned magic_for(unsigned d) { return 0xFFFFFFFFu / d + 1; }
+
 __global__ __launch_bounds__(256) void unpack_pl16_kernel(const uint16_t *__restrict__ pl, const int32_t *__restrict__ col_of_member,
                                                           const double *__restrict__ lut, int n_members, int n_seq,
                                                           long n_sites, double *__restrict__ lk) {
-  const long total = n_sites * n_members * 3;
-  const int w3 = 3 * n_members;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const long s = e / w3;
-    const int r = (int)(e - s * w3), i = r / 3, g = r - 3 * i;
-    const int c = col_of_member[i];
-    double v = 1.0;  // unsequenced member, or sequenced but missing at this site (all three PLs 0xFFFF)
-    if (c >= 0) {
-      const uint16_t *p = pl + (s * n_seq + c) * 3;
-      const uint16_t a = p[0], b = p[1], d = p[2];
-      if (!(a == kPlMissing && b == kPlMissing && d == kPlMissing)) {
-        const uint16_t x = g == 0 ? a : (g == 1 ? b : d);
-        v = x < kPlLutSize ? lut[x] : 0.0;
+  const unsigned w3 = 3 * n_members, mw3 = magic_for(w3);
+  const long tiles = (n_sites + kTileSites - 1) / kTileSites;
+  for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const long site0 = t * kTileSites;
+    const unsigned ns = n_sites - site0 < kTileSites ? (unsigned)(n_sites - site0) : kTileSites;
+    const unsigned nel = ns * w3;
+    const uint16_t *plt = pl + site0 * n_seq * 3;
+    double *lkt = lk + site0 * w3;
+    for (unsigned e = threadIdx.x; e < nel; e += 256) {
+      const unsigned s = div_small(e, mw3), r = e - s * w3, i = (r * 171) >> 9, g = r - 3 * i;
+      const int c = col_of_member[i];
+      double v = 1.0;  // unsequenced member, or sequenced but missing at this site (all three PLs 0xFFFF)
+      if (c >= 0) {
+        const uint16_t *p = plt + (s * n_seq + c) * 3;
+        const uint16_t a = p[0], b = p[1], d = p[2];
+        if (!(a == kPlMissing && b == kPlMissing && d == kPlMissing)) {
+          const uint16_t x = g == 0 ? a : (g == 1 ? b : d);
+          v = x < kPlLutSize ? lut[x] : 0.0;
+        }
       }
+      lkt[e] = v;
     }
-    lk[e] = v;
   }
 }
 
@@ -51,34 +67,39 @@ __global__ __launch_bounds__(256) void phred_call_kernel(const double *__restric
                                                          const int32_t *__restrict__ seq_members, int n_members, int n_seq,
                                                          long n_sites, double *__restrict__ gpp, double *__restrict__ fpp,
                                                          int8_t *__restrict__ fgt) {
-  const long total = n_sites * n_seq * 3;
-  const int w3 = 3 * n_seq;
+  const unsigned w3 = 3 * n_seq, mw3 = magic_for(w3);
   const double nan = __builtin_nan("");
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const long s = e / w3;
-    const int r = (int)(e - s * w3), k = r / 3, g = r - 3 * k;
-    const long src = (s * n_members + seq_members[k]) * 3;
-    const int st = status[s] & 3;
-    gpp[e] = st == 1 ? nan : phred(single[src + g]);
-    fpp[e] = st != 0 ? nan : phred(post[src + g]);
-    if (g == 0) {
-      int8_t pick = -1;
-      if (st == 0) {
-        double best = -1;
-        for (int h = 0; h < 3; ++h)
-          if (best < post[src + h]) {
-            best = post[src + h];
-            pick = (int8_t)h;
-          }
+  const long tiles = (n_sites + kTileSites - 1) / kTileSites;
+  for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const long site0 = t * kTileSites;
+    const unsigned ns = n_sites - site0 < kTileSites ? (unsigned)(n_sites - site0) : kTileSites;
+    const unsigned nel = ns * w3;
+    const double *postt = post + site0 * n_members * 3, *singlet = single + site0 * n_members * 3;
+    for (unsigned e = threadIdx.x; e < nel; e += 256) {
+      const unsigned s = div_small(e, mw3), r = e - s * w3, k = (r * 171) >> 9, g = r - 3 * k;
+      const unsigned src = (s * n_members + seq_members[k]) * 3;
+      const int st = status[site0 + s] & 3;
+      gpp[site0 * w3 + e] = st == 1 ? nan : phred(singlet[src + g]);
+      fpp[site0 * w3 + e] = st != 0 ? nan : phred(postt[src + g]);
+      if (g == 0) {
+        int8_t pick = -1;
+        if (st == 0) {
+          double best = -1;
+          for (int h = 0; h < 3; ++h)
+            if (best < postt[src + h]) {
+              best = postt[src + h];
+              pick = (int8_t)h;
+            }
+        }
+        fgt[(site0 + s) * n_seq + k] = pick;
       }
-      fgt[s * n_seq + k] = pick;
     }
   }
 }
 
-int grid_for(long total) {
-  const long blocks = (total + 255) / 256;
-  return (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
+int grid_for(long n_sites) {
+  const long tiles = (n_sites + kTileSites - 1) / kTileSites;
+  return (int)(tiles < 1 ? 1 : (tiles > 16384 ? 16384 : tiles));
 }
 
 }  // namespace
@@ -86,7 +107,8 @@ int grid_for(long total) {
 hipError_t launch_unpack_pl16(const uint16_t *d_pl, const int32_t *d_col_of_member, const double *d_lut, int n_members,
                               int n_seq, int64_t n_sites, double *d_lk, hipStream_t stream) {
   if (n_sites <= 0) return hipSuccess;
-  hipLaunchKernelGGL(unpack_pl16_kernel, dim3(grid_for(n_sites * n_members * 3)), dim3(256), 0, stream, d_pl,
+  if (n_members < 1 || n_members > 20) return hipErrorInvalidValue;  // div_small's range
+  hipLaunchKernelGGL(unpack_pl16_kernel, dim3(grid_for(n_sites)), dim3(256), 0, stream, d_pl,
                      d_col_of_member, d_lut, n_members, n_seq, (long)n_sites, d_lk);
   return hipGetLastError();
 }
@@ -95,7 +117,8 @@ hipError_t launch_phred_call(const double *d_post, const double *d_single, const
                              const int32_t *d_seq_members, int n_members, int n_seq, int64_t n_sites, double *d_gpp,
                              double *d_fpp, int8_t *d_fgt, hipStream_t stream) {
   if (n_sites <= 0 || n_seq <= 0) return hipSuccess;
-  hipLaunchKernelGGL(phred_call_kernel, dim3(grid_for(n_sites * n_seq * 3)), dim3(256), 0, stream, d_post, d_single,
+  if (n_seq > 20 || n_members > 20) return hipErrorInvalidValue;  // div_small's range
+  hipLaunchKernelGGL(phred_call_kernel, dim3(grid_for(n_sites)), dim3(256), 0, stream, d_post, d_single,
                      d_status, d_seq_members, n_members, n_seq, (long)n_sites, d_gpp, d_fpp, d_fgt);
   return hipGetLastError();
 }
