@@ -96,6 +96,21 @@ void validate_model(const famseq_model &m) {
     if ((mo < 0) != (fa < 0)) throw std::runtime_error("member with exactly one known parent");
     if (mo >= n || fa >= n) throw std::runtime_error("parent index out of range");
   }
+  // nobody may be their own ancestor: generation numbers must settle within n rounds
+  std::vector<int> depth(n, 0);
+  for (int pass = 0; pass <= n; ++pass) {
+    bool moved = false;
+    for (int i = 0; i < n; ++i)
+      if (m.mother[i] >= 0) {
+        const int d = 1 + std::max(depth[m.mother[i]], depth[m.father[i]]);
+        if (d > depth[i]) {
+          depth[i] = d;
+          moved = true;
+        }
+      }
+    if (!moved) return;
+  }
+  throw std::runtime_error("pedigree has a member who is their own ancestor");
 }
 
 void free_slots(famseq_ctx *c) {
@@ -338,7 +353,12 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
     c->engine = (int)value;
     return 0;
   }
-  else if (k == "chunk_sites") { c->chunk_sites = value; free_slots(c); return 0; }
+  else if (k == "chunk_sites") {
+    if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
+    c->chunk_sites = value;
+    free_slots(c);
+    return 0;
+  }
   else return fail(c, FAMSEQ_E_ARG, "unknown option " + k);
   c->plan_dirty = true;
   const int rc = refresh_plan(c);
@@ -352,13 +372,25 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
   return rc;
 }
 
+namespace {
+std::string json_str(const std::string &v) {  // paths may hold quotes or backslashes
+  std::string o;
+  for (char ch : v) {
+    if (ch == '"' || ch == '\\') o += '\\';
+    if ((unsigned char)ch < 0x20) continue;
+    o += ch;
+  }
+  return o;
+}
+}  // namespace
+
 extern "C" const char *famseq_plan_json(famseq_ctx *c) {
   if (!c) return "{}";
   c->json = c->plan.json();
   c->json.pop_back();
   c->json += ",\"engine\":" + std::to_string(c->engine) + ",\"elim_supported\":" +
-             std::string(elim_supported(c->model, nullptr) ? "1" : "0") + ",\"elim_code_object\":\"" + c->elim.path +
-             "\",\"enum_lane_shape\":\"" + enumgen_describe(c->model) + "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + c->lane.path +
+             std::string(elim_supported(c->model, nullptr) ? "1" : "0") + ",\"elim_code_object\":\"" + json_str(c->elim.path) +
+             "\",\"enum_lane_shape\":\"" + enumgen_describe(c->model) + "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + json_str(c->lane.path) +
              "\",\"enum_lane_failed\":" + std::string(c->lane_failed ? "1" : "0") + ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
              ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + ",\"elim_variant\":" + std::to_string(c->elim_variant) +
              ",\"elim_blocks_per_cu\":" + std::to_string(c->elim_blocks_per_cu) + ",\"enum_lane_variant\":" +
@@ -406,6 +438,8 @@ int set_sequenced(famseq_ctx *c, const int32_t *seq, int n_seq) {
   return 0;
 }
 
+int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int64_t chunk);
+
 // Chunked host pipeline shared by every host-buffer entry point: per chunk, on one of two
 // streams, H2D -> [unpack] -> posterior kernel -> [phred/call] -> D2H; the two streams overlap
 // the copies of one chunk with the compute of the other.
@@ -445,6 +479,20 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
     HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_lut), lut.size() * sizeof(double)));
     HIP_TRY(c, hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
   }
+  // From here on copies into the caller's buffers may be in flight: an error must not return
+  // before both streams have drained.
+  const int rc = run_chunks(c, n_sites, io, n_seq, chunk);
+  for (int s = 0; s < famseq_ctx::kSlots; ++s) {
+    const hipError_t e = hipStreamSynchronize(c->stream[s]);
+    if (e != hipSuccess && rc == 0) return fail(c, FAMSEQ_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+  }
+  return rc;
+}
+
+int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int64_t chunk) {
+  const int N = c->plan.N;
+  const size_t row = size_t(3) * N * sizeof(double);
+  const bool called = io.gpp || io.fpp || io.fgt;
   int k = 0;
   for (int64_t lo = 0; lo < n_sites; lo += chunk, ++k) {
     const int s = k % famseq_ctx::kSlots;
@@ -475,7 +523,6 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
     if (io.single) HIP_TRY(c, hipMemcpyAsync(io.single + lo * 3 * N, c->d_single[s], n * row, hipMemcpyDeviceToHost, st));
     if (io.status) HIP_TRY(c, hipMemcpyAsync(io.status + lo, c->d_status[s], n, hipMemcpyDeviceToHost, st));
   }
-  for (int s = 0; s < famseq_ctx::kSlots; ++s) HIP_TRY(c, hipStreamSynchronize(c->stream[s]));
   return 0;
 }
 

@@ -74,6 +74,14 @@ def test_model_init_rejects_like_the_reference():
         sex.relations()
 
 
+def test_create_rejects_a_pedigree_with_a_cycle():
+    """Not a case the reference guards (it would walk such a file as it stands); the generators
+    order members by generation, so a member who is their own ancestor is refused up front."""
+    ped = fs.Pedigree([1, 2, 3, 4], [3, 0, 1, 0], [4, 0, 2, 0], [2, 1, 2, 1], ["a", "b", "c", "d"])
+    with pytest.raises(fs.FamseqError, match="own ancestor"):
+        fs.Context(fs.make_model(ped), device=-1)
+
+
 def test_call_genotypes_first_max_wins():
     g = fs.call_genotypes([[0.2, 0.5, 0.3], [0.5, 0.5, 0.0], [0.1, 0.1, 0.8], [float("nan")] * 3])
     assert g.tolist() == [1, 0, 2, -1]
