@@ -24,8 +24,10 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <charconv>
 #include <sstream>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <vector>
 
@@ -51,9 +53,26 @@ vector<string> split_keep(const string &s, char sep) {
   return out;
 }
 
+// the same split without copies: views into `s` (valid while `s` lives)
+void split_views(std::string_view s, char sep, vector<std::string_view> &out) {
+  out.clear();
+  if (s.empty()) return;
+  size_t head = 0, tail;
+  while ((tail = s.find(sep, head)) != std::string_view::npos) {
+    out.push_back(s.substr(head, tail - head));
+    head = tail + 1;
+  }
+  out.push_back(s.substr(head));
+}
+
 // default ostream formatting of a double (precision 6, general)
 void put_double(string &out, double v) {
   char buf[40];
+  if (std::isfinite(v)) {  // std::to_chars(general, 6) is printf's %g, exactly, at a third of the cost
+    const std::to_chars_result r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::general, 6);
+    out.append(buf, size_t(r.ptr - buf));
+    return;
+  }
   std::snprintf(buf, sizeof buf, "%g", v);
   out += buf;
 }
@@ -332,11 +351,17 @@ bool read_ped(const string &path, Ped &p) {  // file.cpp:24-62
 // ---- batched caller: queue of output records, flushed through the GPU in order -------------
 
 struct Record {
-  string text;              // literal line, or the prefix of a computed line (cols 1-8 + FORMAT + tags)
-  long site = -1;           // index into the pending batch, -1 for literal records
-  vector<string> fields;    // per sequenced sample: original text to print before ':'
-  vector<string> fail_fields;  // per sequenced sample: text for the :NA:NA:NA line (vsLine[9+i] / vsLine[i])
-  string raw;               // the input line, for the warning on failure
+  string text;     // literal line (site < 0); unused for computed lines
+  long site = -1;  // index into the pending batch, -1 for literal records
+  string raw;      // the input line: computed lines print pieces of it (and the failure warning all of it)
+  uint32_t prefix_len = 0;  // columns 1-9 of raw, without the tab after FORMAT (vcf mode)
+  const char *head = nullptr;  // LK mode: a fixed first column instead
+  uint32_t n_fmt = 0;       // FORMAT keys: a missing sample prints that many "NA:"
+  struct Sample {
+    uint32_t off, len;  // the sample's field in raw
+    bool missing;       // shorter than 5 characters (file.cpp:565): printed as NA per FORMAT key
+  };
+  vector<Sample> samples;  // sequenced samples, in output column order
 };
 
 class BatchCaller {
@@ -383,15 +408,31 @@ class BatchCaller {
     parallel_for(q_.size(), [&](size_t i) {
       const Record &r = q_[i];
       string &line = lines[i];
-      line.assign(r.text);
-      if (r.site >= 0) {
+      if (r.site < 0) {
+        line.assign(r.text);
+      } else {
+        if (r.head) {
+          line.assign(r.head);
+        } else {
+          line.assign(r.raw, 0, r.prefix_len);  // columns 1-8 + FORMAT
+          line += ":GPP:FPP:FGT\t";
+        }
         if (status_[r.site] & 3) {  // file.cpp:607-620
-          for (const string &f : r.fail_fields) line += f + ":NA:NA:NA\t";
+          for (const Record::Sample &sm : r.samples) {
+            line.append(r.raw, sm.off, sm.len);
+            line += ":NA:NA:NA\t";
+          }
         } else {
           for (size_t j = 0; j < k; ++j) {
             const double *g = &gpp_[(size_t(r.site) * k + j) * 3], *f = &fpp_[(size_t(r.site) * k + j) * 3];
             const int gt = fgt_[size_t(r.site) * k + j];
-            line += r.fields[j];
+            const Record::Sample &sm = r.samples[j];
+            if (sm.missing) {
+              for (uint32_t q = 0; q < r.n_fmt; ++q) line += "NA:";
+            } else {
+              line.append(r.raw, sm.off, sm.len);
+              line += ':';
+            }
             put_double(line, g[0]); line += ',';
             put_double(line, g[1]); line += ',';
             put_double(line, g[2]); line += ':';
@@ -771,96 +812,128 @@ bool run_vcf(const Options &o, const Ped &ped) {
   BatchCaller caller(ctx, ped.n(), seq_members, fout, batch_capacity());
   const PlTable pl;
   const size_t n_seq = seq_cols.size();
-  vector<double> lk(size_t(3) * ped.n());
-  vector<uint16_t> pl16(3 * n_seq);
   bool ok = true;
 
-  auto echo = [&](const vector<string> &t) {  // the "allLine" echo: 9 columns + sequenced samples
-    if (o.pack_mode) return;
-    string s;
-    for (int i = 0; i < 9; i++) s += t[i] + '\t';
-    for (int c : seq_cols) s += t[9 + c] + '\t';
-    caller.literal(std::move(s));
+  // One input line -> what to do with it.  Pure function of the line (no shared state), so a block
+  // of lines is parsed on all host cores and then applied in input order.
+  struct Parsed {
+    enum Kind { kDrop, kEcho, kSite } kind = kDrop;
+    string echo;  // kEcho: the "allLine" echo (9 columns + sequenced samples)
+    Record rec;   // kSite
+    vector<double> lk;
+    vector<uint16_t> pl16;
+    bool integral = true;
+    uint8_t flags = 0;
   };
-
-  for (; have_line && ok; have_line = bool(std::getline(fin, line))) {
-    if (line.size() < 2) break;
-    if (line[0] == '#') continue;
-    const vector<string> t = split_keep(line, '\t');
-    if (t.size() < 9 + ncol) continue;  // malformed line (the reference would read out of bounds)
+  auto parse_line = [&](string &line, Parsed &out) {
+    out.kind = Parsed::kDrop;
+    if (line[0] == '#') return;
+    thread_local vector<std::string_view> t, fmt, sub;
+    split_views(line, '\t', t);
+    if (t.size() < 9 + ncol) return;  // malformed line (the reference would read out of bounds)
+    auto echo = [&] {
+      if (o.pack_mode) return;
+      out.kind = Parsed::kEcho;
+      out.echo.clear();
+      for (int i = 0; i < 9; i++) (out.echo += t[i]) += '\t';
+      for (int c : seq_cols) (out.echo += t[9 + c]) += '\t';
+    };
     if (use_loc) {
-      const int c = chrom_number(t[0]);
-      const int p = std::atoi(t[1].c_str());
-      if (c < 1 || c > 25 || p == 0) continue;
-      if (!std::binary_search(loc[c - 1].begin(), loc[c - 1].end(), p)) continue;
+      const int c = chrom_number(string(t[0]));
+      const int p = std::atoi(string(t[1]).c_str());
+      if (c < 1 || c > 25 || p == 0) return;
+      if (!std::binary_search(loc[c - 1].begin(), loc[c - 1].end(), p)) return;
     }
     // site rules, in the reference's order (file.cpp:362-473)
     if (t[3] == "." || t[3] == "-" || t[3].size() != 1 || t[4].size() != 1) {
-      if (o.all_line) echo(t);
-      continue;
+      if (o.all_line) echo();
+      return;
     }
-    if (o.var_only && (t[4] == "." || t[4] == "-")) continue;
+    if (o.var_only && (t[4] == "." || t[4] == "-")) return;
     if (t[0] == "Y" || t[0] == "chrY" || t[0] == "MT") {
-      if (o.all_line) echo(t);
-      continue;
+      if (o.all_line) echo();
+      return;
     }
     const bool is_x = t[0] == "X" || t[0] == "chrX" || t[0] == "CHRX";
-    const int cn = std::atoi(t[0].compare(0, 3, "chr") == 0 ? t[0].c_str() + 3 : t[0].c_str());
+    const string chrom(t[0]);
+    const int cn = std::atoi(chrom.compare(0, 3, "chr") == 0 ? chrom.c_str() + 3 : chrom.c_str());
     if (!((0 < cn && cn < 23) || is_x)) {
-      if (o.all_line) echo(t);
-      continue;
+      if (o.all_line) echo();
+      return;
     }
-    const uint8_t flags = uint8_t((t[2] != "." ? FAMSEQ_FLAG_KNOWN : 0) | (is_x ? FAMSEQ_FLAG_CHRX : 0));
-    const vector<string> fmt = split_keep(t[8], ':');
+    out.flags = uint8_t((t[2] != "." ? FAMSEQ_FLAG_KNOWN : 0) | (is_x ? FAMSEQ_FLAG_CHRX : 0));
+    split_views(t[8], ':', fmt);
     size_t n_miss = 0;
     for (int c : seq_cols) n_miss += t[9 + c].size() < 5;
     if (n_miss == n_seq) {
-      if (o.all_line) echo(t);
-      continue;
+      if (o.all_line) echo();
+      return;
     }
     int i_pl = -1;
     for (size_t k = 0; k < fmt.size(); k++)
       if (fmt[k] == "PL" || fmt[k] == "GL") i_pl = (int)k;
     if (i_pl < 0) {  // echoed unchanged even without -a (file.cpp:541-555, :770-784)
-      echo(t);
-      continue;
+      echo();
+      return;
     }
-    Record r;
-    for (int i = 0; i < 8; i++) r.text += t[i] + '\t';
-    r.text += t[8] + ":GPP:FPP:FGT\t";
-    r.raw = line;
-    std::fill(lk.begin(), lk.end(), 1.0);
-    std::fill(pl16.begin(), pl16.end(), uint16_t(0xFFFF));  // 0xFFFF x3 = missing sample
-    bool integral = true;
+    out.kind = Parsed::kSite;
+    Record &r = out.rec;
+    r = Record();
+    const char *base = line.data();
+    r.prefix_len = uint32_t(t[8].data() + t[8].size() - base);
+    r.n_fmt = uint32_t(fmt.size());
+    out.lk.assign(size_t(3) * ped.n(), 1.0);
+    out.pl16.assign(3 * n_seq, uint16_t(0xFFFF));  // 0xFFFF x3 = missing sample
+    out.integral = true;
     size_t col = 0;
     for (int c : seq_cols) {
       const size_t this_col = col++;
-      const string &f = t[9 + c];
-      r.fail_fields.push_back(f);
-      if (f.size() < 5) {  // missing sample: flat likelihood, printed as NA per FORMAT key (file.cpp:927-933)
-        string na;
-        for (size_t k = 0; k < fmt.size(); k++) na += "NA:";
-        r.fields.push_back(na);
-        continue;
-      }
-      r.fields.push_back(f + ":");
-      const vector<string> sub = split_keep(f, ':');
+      const std::string_view f = t[9 + c];
+      r.samples.push_back({uint32_t(f.data() - base), uint32_t(f.size()), f.size() < 5});
+      if (f.size() < 5) continue;  // missing sample: flat likelihood (file.cpp:927-933)
+      split_views(f, ':', sub);
       if (sub.size() != fmt.size()) continue;  // row stays {1,1,1} (file.cpp:573-578)
-      const string &pls = sub[i_pl];
-      const char *b = pls.c_str(), *end = b + pls.size();
+      const std::string_view pls = sub[i_pl];
+      const char *b = pls.data(), *end = b + pls.size();
       for (int g = 0; g < 3; g++) {
         const char *e = static_cast<const char *>(std::memchr(b, ',', size_t(end - b)));
         if (!e) e = end;
-        lk[size_t(3) * v2p[c] + g] = pl(b, e, &pl16[3 * this_col + g], &integral);
+        out.lk[size_t(3) * v2p[c] + g] = pl(b, e, &out.pl16[3 * this_col + g], &out.integral);
         b = e < end ? e + 1 : end;
       }
     }
-    if (o.pack_mode) {
-      if (integral) packer.add(flags, pl16.data());
-      else packer.skipped++;
-      continue;
+    r.raw = std::move(line);  // last: the views above point into it (a moved std::string keeps its buffer)
+  };
+
+  const size_t block = std::min<size_t>(batch_capacity(), size_t(1) << 16);
+  vector<string> lines;
+  vector<Parsed> parsed;
+  bool more = have_line;
+  while (more && ok) {
+    lines.clear();
+    while (more && lines.size() < block) {  // `line` holds the next unread line
+      if (line.size() < 2) {  // the reference stops at the first empty line
+        more = false;
+        break;
+      }
+      lines.push_back(std::move(line));
+      more = bool(std::getline(fin, line));
     }
-    ok = caller.site(std::move(r), lk, integral ? pl16.data() : nullptr, flags);
+    if (parsed.size() < lines.size()) parsed.resize(lines.size());
+    parallel_for(lines.size(), [&](size_t i) { parse_line(lines[i], parsed[i]); });
+    for (size_t i = 0; i < lines.size() && ok; ++i) {
+      Parsed &q = parsed[i];
+      if (q.kind == Parsed::kEcho) {
+        caller.literal(std::move(q.echo));
+      } else if (q.kind == Parsed::kSite) {
+        if (o.pack_mode) {
+          if (q.integral) packer.add(q.flags, q.pl16.data());
+          else packer.skipped++;
+        } else {
+          ok = caller.site(std::move(q.rec), q.lk, q.integral ? q.pl16.data() : nullptr, q.flags);
+        }
+      }
+    }
   }
   if (o.pack_mode) {
     std::cout << packer.n_sites << " sites packed";
@@ -918,16 +991,15 @@ bool run_lk(const Options &o, const Ped &ped) {
   bool ok = true;
   while (ok && std::getline(fin, line)) {
     if (line.size() < 2) break;
-    const vector<string> t = split_keep(line, '\t');
+    vector<std::string_view> t;
+    split_views(line, '\t', t);
     if (!seq_cols.empty() && t.size() <= size_t(seq_cols.back())) continue;  // short row
     std::fill(lk.begin(), lk.end(), 1.0);
     Record r;
-    r.text = "LK:GPP:FPP:FGT\t";
-    r.raw = line;
+    r.head = "LK:GPP:FPP:FGT\t";
     for (int c : seq_cols) {
-      r.fields.push_back(t[c] + ":");
-      r.fail_fields.push_back(t[c]);
-      const vector<string> v = split_keep(t[c], ',');
+      r.samples.push_back({uint32_t(t[c].data() - line.data()), uint32_t(t[c].size()), false});
+      const vector<string> v = split_keep(string(t[c]), ',');
       for (int g = 0; g < 3 && g < (int)v.size(); g++) {
         double x = std::atof(v[g].c_str());
         if (o.lk_type == 2) x = std::pow(10.0, x);
@@ -936,6 +1008,7 @@ bool run_lk(const Options &o, const Ped &ped) {
         lk[size_t(3) * v2p[c] + g] = x;
       }
     }
+    r.raw = line;
     ok = caller.site(std::move(r), lk, nullptr, 0);  // calPostProbBN() defaults: Known=false, chrType=0 (file.cpp:1751)
   }
   ok = ok && caller.flush();
