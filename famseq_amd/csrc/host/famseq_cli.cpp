@@ -905,24 +905,35 @@ bool run_vcf(const Options &o, const Ped &ped) {
     r.raw = std::move(line);  // last: the views above point into it (a moved std::string keeps its buffer)
   };
 
+  // Two blocks in rotation: while one is applied (GPU batch, formatting, output) the next is read
+  // and parsed by a helper thread.  Only the helper touches `fin` / `line`; only this thread
+  // touches the caller, the packer and the output.
   const size_t block = std::min<size_t>(batch_capacity(), size_t(1) << 16);
-  vector<string> lines;
-  vector<Parsed> parsed;
+  struct Block {
+    vector<string> lines;
+    vector<Parsed> parsed;
+  } blocks[2];
   bool more = have_line;
-  while (more && ok) {
-    lines.clear();
-    while (more && lines.size() < block) {  // `line` holds the next unread line
-      if (line.size() < 2) {  // the reference stops at the first empty line
+  auto load = [&](Block &b) {
+    b.lines.clear();
+    while (more && b.lines.size() < block) {  // `line` holds the next unread line
+      if (line.size() < 2) {                  // the reference stops at the first empty line
         more = false;
         break;
       }
-      lines.push_back(std::move(line));
+      b.lines.push_back(std::move(line));
       more = bool(std::getline(fin, line));
     }
-    if (parsed.size() < lines.size()) parsed.resize(lines.size());
-    parallel_for(lines.size(), [&](size_t i) { parse_line(lines[i], parsed[i]); });
-    for (size_t i = 0; i < lines.size() && ok; ++i) {
-      Parsed &q = parsed[i];
+    if (b.parsed.size() < b.lines.size()) b.parsed.resize(b.lines.size());
+    parallel_for(b.lines.size(), [&](size_t i) { parse_line(b.lines[i], b.parsed[i]); });
+  };
+  int cur = 0;
+  load(blocks[cur]);
+  while (!blocks[cur].lines.empty() && ok) {
+    std::thread ahead([&, cur] { load(blocks[1 - cur]); });
+    Block &b = blocks[cur];
+    for (size_t i = 0; i < b.lines.size() && ok; ++i) {
+      Parsed &q = b.parsed[i];
       if (q.kind == Parsed::kEcho) {
         caller.literal(std::move(q.echo));
       } else if (q.kind == Parsed::kSite) {
@@ -934,6 +945,8 @@ bool run_vcf(const Options &o, const Ped &ped) {
         }
       }
     }
+    ahead.join();
+    cur = 1 - cur;
   }
   if (o.pack_mode) {
     std::cout << packer.n_sites << " sites packed";
