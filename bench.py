@@ -316,11 +316,17 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms": kernel_ms,
                          "bytes_per_site": bytes_per_site,
-                         "read_GBps": S * (24 * n + 1) / (kernel_ms * 1e-3) / 1e9},
+                         "read_GBps": S * (24 * n + 1) / (kernel_ms * 1e-3) / 1e9,
+                         "frac_of_measured_copy_6290GBps": achieved / 6290.0},
             "fp64_valu": {"achieved": S * ops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TOPS,
                           "unit": "T fp64 FMA/s (one per joint configuration)",
                           "frac": S * ops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
-                          "configs_per_site": ops, "configs_per_s": S * 3 ** n / (kernel_ms * 1e-3)},
+                          "configs_per_site": ops, "configs_per_s": S * 3 ** n / (kernel_ms * 1e-3),
+                          # the odometer's work, 2N fp64 ops per configuration, had it been done
+                          # without shared prefixes (its 100 %-VALU bound is 39.3e12 / (2N 3^N) sites/s)
+                          "naive_2N_ops_per_config_Tops": S * 2 * n * 3 ** n / (kernel_ms * 1e-3) / 1e12,
+                          "x_over_naive_valu_bound": S / (kernel_ms * 1e-3) / (FP64_VALU_PEAK_TOPS * 1e12 / (2 * n * 3 ** n)),
+                          "sustained_2_waves_per_simd": "32.9 T/s measured on a pure FMA stream (tools/fp64_latency.hip)"},
         }
         if a.lc != 1.0:  # an experiment, not the BASELINE workload: say so where the judge reads the workload
             out["config"]["workload"] = "EXPERIMENT -LRC %g (sites below the cut-off skip the BN posterior); " % a.lc \
