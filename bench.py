@@ -196,7 +196,22 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL carries only the barrier and the max-over-ranks of the timing (the data path has no
+            # collective).  If it cannot come up on this node, the same two calls go over gloo rather
+            # than losing the run: every rank sees the same environment, so all of them take this turn.
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                dist.barrier()
+            except Exception as e:  # noqa: BLE001
+                print("bench.py: RCCL unavailable (%s); barrier/timing reduction over gloo" % str(e).splitlines()[0],
+                      file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                a.backend, red_dev = "gloo", torch.device("cpu")
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group("gloo")
 
@@ -309,6 +324,7 @@ def main():
                                    "(3^%d = %d configs/site), -method 1 BN posterior, every site takes the full enumeration"
                                    % (CONFIG_OF[a.workload], a.workload, S, n, n, 3 ** n),
                        "sites_per_gpu": S, "global_sites": total_sites, "parallelism": "sites sharded x%d, no collective" % world,
+                       "barrier_backend": (a.backend if world > 1 else None),
                        "engine": a.engine, "lane_kernel_tiling": plan.get("enum_lane_shape"),
                        "team_kernel_plan": {k: plan[k] for k in ("L", "A", "J", "team_lanes", "teams_per_block", "block_threads",
                                                                  "lds_bytes", "blocks_per_cu")}},
