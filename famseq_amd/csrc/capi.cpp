@@ -51,9 +51,12 @@ struct famseq_ctx {
   // device constants
   uint32_t *d_img = nullptr;
   double *d_tc = nullptr;
-  // staging for the host-buffer entry point: two slots so copies overlap compute
+  // staging for the host-buffer entry point: a three-stage pipeline (copy in / compute / copy out,
+  // one stream each, so both directions of the host link run at once) over two buffer slots
   static constexpr int kSlots = 2;
-  hipStream_t stream[kSlots] = {nullptr, nullptr};
+  static constexpr int kStages = 3;
+  hipStream_t stream[kStages] = {nullptr, nullptr, nullptr};  // 0 copy in, 1 compute, 2 copy out
+  hipEvent_t ev_in[kSlots] = {}, ev_done[kSlots] = {}, ev_out[kSlots] = {};
   int64_t slot_sites = 0;
   double *d_lk[kSlots] = {}, *d_post[kSlots] = {}, *d_single[kSlots] = {};
   uint8_t *d_flags[kSlots] = {}, *d_status[kSlots] = {};
@@ -294,12 +297,19 @@ extern "C" famseq_ctx *famseq_create(const famseq_model *model, int device_id, c
     }
     c->device = device_id;
     c->n_cus = prop.multiProcessorCount;
-    for (int s = 0; s < famseq_ctx::kSlots; ++s)
+    for (int s = 0; s < famseq_ctx::kStages; ++s)
       if ((e = hipStreamCreateWithFlags(&c->stream[s], hipStreamNonBlocking)) != hipSuccess) {
         set_err(err, errlen, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         famseq_destroy(c);
         return nullptr;
       }
+    for (int s = 0; s < famseq_ctx::kSlots; ++s)
+      for (hipEvent_t *ev : {&c->ev_in[s], &c->ev_done[s], &c->ev_out[s]})
+        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) {
+          set_err(err, errlen, std::string("hipEventCreate: ") + hipGetErrorString(e));
+          famseq_destroy(c);
+          return nullptr;
+        }
   }
   if (refresh_plan(c) != 0) {
     set_err(err, errlen, c->err);
@@ -321,8 +331,11 @@ extern "C" void famseq_destroy(famseq_ctx *c) {
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_seq) (void)hipFree(c->d_seq);
     if (c->d_col) (void)hipFree(c->d_col);
-    for (int s = 0; s < famseq_ctx::kSlots; ++s)
+    for (int s = 0; s < famseq_ctx::kStages; ++s)
       if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
+    for (int s = 0; s < famseq_ctx::kSlots; ++s)
+      for (hipEvent_t ev : {c->ev_in[s], c->ev_done[s], c->ev_out[s]})
+        if (ev) (void)hipEventDestroy(ev);
   }
   delete c;
 }
@@ -440,9 +453,10 @@ int set_sequenced(famseq_ctx *c, const int32_t *seq, int n_seq) {
 
 int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int64_t chunk);
 
-// Chunked host pipeline shared by every host-buffer entry point: per chunk, on one of two
-// streams, H2D -> [unpack] -> posterior kernel -> [phred/call] -> D2H; the two streams overlap
-// the copies of one chunk with the compute of the other.
+// Chunked host pipeline shared by every host-buffer entry point: per chunk H2D -> [unpack] ->
+// posterior kernel -> [phred/call] -> D2H, each stage on its own stream and chained by events, so
+// that chunk k+1 is copied in while chunk k is copied out (two chunk-sized streams running the
+// whole sequence each fell into lockstep and used one direction of the link at a time).
 int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
   if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
   if (n_sites == 0) return 0;
@@ -450,11 +464,17 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
   const int N = c->plan.N;
   const size_t row = size_t(3) * N * sizeof(double);
   const bool called = io.gpp || io.fpp || io.fgt;
-  int64_t chunk = c->chunk_sites > 0 ? c->chunk_sites : std::max<int64_t>(1, (int64_t(64) << 20) / int64_t(row));
+  // default chunk: at most 64 MiB per array, at least four chunks per call so that the stages overlap,
+  // but not below the batch size the lane-per-site kernel needs to fill the chip
+  int64_t chunk = c->chunk_sites;
+  if (chunk <= 0) {
+    chunk = std::max<int64_t>(1, (int64_t(64) << 20) / int64_t(row));
+    chunk = std::min(chunk, std::max<int64_t>(c->lane_min_sites, (n_sites + 3) / 4));
+  }
   chunk = std::min(chunk, n_sites);
   const int want_seq = (io.pl16 || called) ? std::max(n_seq, 1) : 0;
   if (c->slot_sites < chunk || c->slot_seq < want_seq) {
-    const int64_t cap = std::max(chunk, c->slot_sites);
+    const int64_t cap = std::max(chunk, c->slot_sites);  // slots only grow: varying batch sizes do not thrash
     const int seqcap = std::max(want_seq, c->slot_seq);
     free_slots(c);
     for (int s = 0; s < famseq_ctx::kSlots; ++s) {
@@ -482,7 +502,7 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
   // From here on copies into the caller's buffers may be in flight: an error must not return
   // before both streams have drained.
   const int rc = run_chunks(c, n_sites, io, n_seq, chunk);
-  for (int s = 0; s < famseq_ctx::kSlots; ++s) {
+  for (int s = 0; s < famseq_ctx::kStages; ++s) {
     const hipError_t e = hipStreamSynchronize(c->stream[s]);
     if (e != hipSuccess && rc == 0) return fail(c, FAMSEQ_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
   }
@@ -493,35 +513,44 @@ int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int6
   const int N = c->plan.N;
   const size_t row = size_t(3) * N * sizeof(double);
   const bool called = io.gpp || io.fpp || io.fgt;
+  hipStream_t s_in = c->stream[0], s_k = c->stream[1], s_out = c->stream[2];
   int k = 0;
   for (int64_t lo = 0; lo < n_sites; lo += chunk, ++k) {
     const int s = k % famseq_ctx::kSlots;
     const int64_t n = std::min(chunk, n_sites - lo);
-    hipStream_t st = c->stream[s];
-    HIP_TRY(c, hipStreamSynchronize(st));  // the slot's previous chunk has fully drained
+    // copy in: the slot is free once the chunk that used it last has been copied out
+    if (k >= famseq_ctx::kSlots) HIP_TRY(c, hipStreamWaitEvent(s_in, c->ev_out[s], 0));
     if (io.pl16) {
       HIP_TRY(c, hipMemcpyAsync(c->d_pl[s], io.pl16 + lo * n_seq * 3, n * n_seq * 3 * sizeof(uint16_t),
-                                hipMemcpyHostToDevice, st));
-      HIP_TRY(c, launch_unpack_pl16(c->d_pl[s], c->d_col, c->d_lut, N, n_seq, n, c->d_lk[s], st));
+                                hipMemcpyHostToDevice, s_in));
     } else {
-      HIP_TRY(c, hipMemcpyAsync(c->d_lk[s], io.lk + lo * 3 * N, n * row, hipMemcpyHostToDevice, st));
+      HIP_TRY(c, hipMemcpyAsync(c->d_lk[s], io.lk + lo * 3 * N, n * row, hipMemcpyHostToDevice, s_in));
     }
-    if (io.flags) HIP_TRY(c, hipMemcpyAsync(c->d_flags[s], io.flags + lo, n, hipMemcpyHostToDevice, st));
+    if (io.flags) HIP_TRY(c, hipMemcpyAsync(c->d_flags[s], io.flags + lo, n, hipMemcpyHostToDevice, s_in));
+    HIP_TRY(c, hipEventRecord(c->ev_in[s], s_in));
+    // compute
+    HIP_TRY(c, hipStreamWaitEvent(s_k, c->ev_in[s], 0));
+    if (io.pl16) HIP_TRY(c, launch_unpack_pl16(c->d_pl[s], c->d_col, c->d_lut, N, n_seq, n, c->d_lk[s], s_k));
     const bool need_single = io.single || io.gpp;
     const bool need_status = io.status || called;
     HIP_TRY(c, launch_engine(c, n, c->d_lk[s], io.flags ? c->d_flags[s] : nullptr, c->d_post[s],
-                             need_single ? c->d_single[s] : nullptr, need_status ? c->d_status[s] : nullptr, st));
-    if (called) {
+                             need_single ? c->d_single[s] : nullptr, need_status ? c->d_status[s] : nullptr, s_k));
+    if (called)
       HIP_TRY(c, launch_phred_call(c->d_post[s], c->d_single[s], c->d_status[s], c->d_seq, N, n_seq, n, c->d_gpp[s],
-                                   c->d_fpp[s], c->d_fgt[s], st));
+                                   c->d_fpp[s], c->d_fgt[s], s_k));
+    HIP_TRY(c, hipEventRecord(c->ev_done[s], s_k));
+    // copy out
+    HIP_TRY(c, hipStreamWaitEvent(s_out, c->ev_done[s], 0));
+    if (called) {
       const size_t cr = size_t(3) * n_seq * sizeof(double);
-      if (io.gpp) HIP_TRY(c, hipMemcpyAsync(io.gpp + lo * 3 * n_seq, c->d_gpp[s], n * cr, hipMemcpyDeviceToHost, st));
-      if (io.fpp) HIP_TRY(c, hipMemcpyAsync(io.fpp + lo * 3 * n_seq, c->d_fpp[s], n * cr, hipMemcpyDeviceToHost, st));
-      if (io.fgt) HIP_TRY(c, hipMemcpyAsync(io.fgt + lo * n_seq, c->d_fgt[s], n * n_seq, hipMemcpyDeviceToHost, st));
+      if (io.gpp) HIP_TRY(c, hipMemcpyAsync(io.gpp + lo * 3 * n_seq, c->d_gpp[s], n * cr, hipMemcpyDeviceToHost, s_out));
+      if (io.fpp) HIP_TRY(c, hipMemcpyAsync(io.fpp + lo * 3 * n_seq, c->d_fpp[s], n * cr, hipMemcpyDeviceToHost, s_out));
+      if (io.fgt) HIP_TRY(c, hipMemcpyAsync(io.fgt + lo * n_seq, c->d_fgt[s], n * n_seq, hipMemcpyDeviceToHost, s_out));
     }
-    if (io.post) HIP_TRY(c, hipMemcpyAsync(io.post + lo * 3 * N, c->d_post[s], n * row, hipMemcpyDeviceToHost, st));
-    if (io.single) HIP_TRY(c, hipMemcpyAsync(io.single + lo * 3 * N, c->d_single[s], n * row, hipMemcpyDeviceToHost, st));
-    if (io.status) HIP_TRY(c, hipMemcpyAsync(io.status + lo, c->d_status[s], n, hipMemcpyDeviceToHost, st));
+    if (io.post) HIP_TRY(c, hipMemcpyAsync(io.post + lo * 3 * N, c->d_post[s], n * row, hipMemcpyDeviceToHost, s_out));
+    if (io.single) HIP_TRY(c, hipMemcpyAsync(io.single + lo * 3 * N, c->d_single[s], n * row, hipMemcpyDeviceToHost, s_out));
+    if (io.status) HIP_TRY(c, hipMemcpyAsync(io.status + lo, c->d_status[s], n, hipMemcpyDeviceToHost, s_out));
+    HIP_TRY(c, hipEventRecord(c->ev_out[s], s_out));
   }
   return 0;
 }

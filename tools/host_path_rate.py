@@ -14,7 +14,24 @@ cfg = {"ped5": 1, "ped10": 2, "ped15": 4}[name]
 lk_t, fl_t = fs.synth.gen_batch_torch(mo.tolist(), fa.tolist(), S, cfg, device="cuda")
 lk, fl = lk_t.cpu().numpy(), fl_t.cpu().numpy()
 ctx = fs.Context(fs.make_model(ped))
-for label, pin in (("pageable", False), ("pinned", True)):
+# what the link itself gives (pinned, one direction at a time, then both at once on two streams)
+h = torch.empty(1 << 27, dtype=torch.uint8).pin_memory()
+d = torch.empty(1 << 27, dtype=torch.uint8, device="cuda")
+h2, d2 = torch.empty_like(h).pin_memory(), torch.empty_like(d)
+def bw(f, n=5):
+    f(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return n * (1 << 27) / (time.perf_counter() - t0) / 1e9
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+def both():
+    with torch.cuda.stream(s1): d.copy_(h, non_blocking=True)
+    with torch.cuda.stream(s2): h2.copy_(d2, non_blocking=True)
+print("link: H2D %.1f GB/s, D2H %.1f GB/s, both at once %.1f GB/s each" % (bw(lambda: d.copy_(h, non_blocking=True)), bw(lambda: h.copy_(d, non_blocking=True)), bw(both)))
+del h, d, h2, d2
+chunks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+for label, pin, chunk in [(l, p_, c) for c in chunks for (l, p_) in (("pageable", False), ("pinned", True))]:
+    ctx.set_option("chunk_sites", chunk)
+    label = "%s chunk=%s" % (label, chunk or "default")
     if pin:
         bufs = [torch.empty(lk.shape, dtype=torch.float64).pin_memory() for _ in range(3)]
         bufs[0].copy_(torch.from_numpy(lk))
