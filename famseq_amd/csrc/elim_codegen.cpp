@@ -92,7 +92,7 @@ bool build_graph(const famseq_model &m, Graph &g, std::string *why) {
 
 class Emitter {
  public:
-  Emitter(const famseq_model &m, const Graph &g, int fences) : m_(m), g_(g), fences_(fences) {}
+  Emitter(const famseq_model &m, const Graph &g, int fences, bool scalar_t) : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t) {}
 
   std::string body() {
     for (int p = 0; p < g_.N; ++p) marginal(p);
@@ -103,6 +103,7 @@ class Emitter {
   const famseq_model &m_;
   const Graph &g_;
   const int fences_;  // 0 none, 1 after every family->member message, 2 also after local factors and child sums
+  const bool scalar_t_;  // transmission entries from tcx[] (uniform pointer: scalar loads) instead of the lane's LDS table
   std::ostringstream o_;
   std::map<std::string, bool> done_;
   int uid_ = 0;
@@ -123,7 +124,7 @@ class Emitter {
     return m_.mother[p] < 0 ? (male ? 0 : 1) : (male ? 2 : 3);
   }
   std::string T(int child, int gc, int gm, int gf) const {
-    return "tcf[" + num(kind(child) * 27 + 9 * gc + 3 * gm + gf) + "]";
+    return std::string(scalar_t_ ? "tcx[" : "tcf[") + num(kind(child) * 27 + 9 * gc + 3 * gm + gf) + "]";
   }
 
   // member-local factor c{p}_g
@@ -255,7 +256,8 @@ int elim_block_threads(const famseq_model &m) {
 //                   message-passing code); the body writes the marginals to q[0..W3) and runs
 //                   BEFORE the single posterior takes over the row.
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
-                         const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single) {
+                         const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
+                         bool chrx_loop) {
   const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1;
   // Prefetching the next chunk costs W3 doubles of registers next to the W3 marginals; on MI355X it
   // pays while it does not spill (ped5: +14 %); beyond the limits below it spills and loses.
@@ -412,10 +414,22 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     // Writing each lane's row straight from registers was measured 20 % slower on MI355X
     // (64 partial-line requests per store instruction), so the extra barriers stay.
     single_pass(true, false);
-    s << "    double q[W3];\n"
-      << "    if (full && !single_fail) {\n"
-      << body << "    }\n"
-      ;
+    s << "    double q[W3];\n";
+    if (chrx_loop) {
+      // The transmission entries depend on the site's chrX bit only.  The body reads them through a
+      // wave-uniform pointer (scalar loads: no LDS traffic, no VGPRs) and runs once per chrX value
+      // present in the wave, with the lanes of that value active — one pass in practice.
+      s << "    {\n      const int chrx_ = fl >> 1;\n"
+        << "#pragma unroll 1\n"
+        << "      for (int x_ = 0; x_ < 2; ++x_) {\n"
+        << "        const bool mine_ = full && !single_fail && chrx_ == x_;\n"
+        << "        if (__builtin_amdgcn_ballot_w64(mine_) == 0) continue;\n"
+        << "        const double *tcx = tc_g + x_ * 216;\n"
+        << "        if (mine_) {\n"
+        << body << "        }\n      }\n    }\n";
+    } else {
+      s << "    if (full && !single_fail) {\n" << body << "    }\n";
+    }
     if (prefetch && !early)
       // software prefetch: issue the next chunk's loads now; they stay in flight while this
       // chunk's two output phases run (the barriers below do not wait for vmcnt)
@@ -444,13 +458,16 @@ std::string elim_source(const famseq_model &m, int variant) {
   const int bt = elim_block_threads(m);
   int min_waves = m.n_members <= 10 ? 2 : 1;
   if (const char *e = std::getenv("FAMSEQ_ELIM_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
+  // From variant 1 on the transmission tables are read through scalar loads (measured: +9 % at 10
+  // members where registers are tight, -7 % on the fence-free 5-member kernel, which keeps the LDS table).
   // variant 0: no compiler fences (most overlap between the message blocks; fits small pedigrees),
   //         1: a fence after every family->member message, 2: also after local factors and child
   //         summaries, 3: also between the members of the single posterior
   return kernel_shell(m, "famseq_elim",
                       "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families, variant " +
                           std::to_string(variant),
-                      Emitter(m, g, variant < 2 ? variant : 2).body(), bt, min_waves, /*regs_l=*/false, variant >= 3);
+                      Emitter(m, g, variant < 2 ? variant : 2, /*scalar_t=*/variant >= 1).body(), bt, min_waves,
+                      /*regs_l=*/false, variant >= 3, /*chrx_loop=*/variant >= 1);
 }
 
 }  // namespace famseq
