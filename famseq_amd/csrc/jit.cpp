@@ -102,6 +102,11 @@ std::string jit_compile(const std::string &source, int *scratch_bytes) {
     if (!f) throw std::runtime_error("cannot write " + src);
   }
   const char *cc = std::getenv("FAMSEQ_HIPCC");
+  // the command line goes through /bin/sh with the paths in single quotes
+  if (dir.find('\'') != std::string::npos || (cc && std::string(cc).find_first_of("'\";|&$`\n") != std::string::npos)) {
+    ::unlink(src.c_str());
+    throw std::runtime_error("kernel cache directory or FAMSEQ_HIPCC holds a shell metacharacter");
+  }
   const std::string cmd = std::string(cc ? cc : "/opt/rocm/bin/hipcc") +
                           " --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --genco"
                           " -Rpass-analysis=kernel-resource-usage -o '" + tmp + "' '" + src +
@@ -138,7 +143,7 @@ std::string jit_pick_variant(const std::function<std::string(int)> &generate, in
   std::string best;
   int best_scratch = -1, best_i = 0;
   int first = 0;
-  if (const char *e = std::getenv("FAMSEQ_VARIANT_MIN")) first = std::min(std::atoi(e), n_variants - 1);  // tuning aid
+  if (const char *e = std::getenv("FAMSEQ_VARIANT_MIN")) first = std::max(0, std::min(std::atoi(e), n_variants - 1));  // tuning aid
   for (int v = first; v < n_variants; ++v) {
     std::string src = generate(v);
     int scratch = -1;
