@@ -92,3 +92,29 @@ def test_plan_replay_matches_oracle(name, opt):
         assert visited == 3 ** c.n
         got = bins / bins.sum(axis=1, keepdims=True)
         np.testing.assert_allclose(got, post[s], rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("name", ["ped5", "ped10", "ped15"])
+def test_generated_lane_kernel_accumulates_every_configuration_once(name, tmp_path, monkeypatch):
+    """Structure of the generated enumeration source: (FMAs into the joint super-leaf accumulators
+    in the unrolled block) x 3^(looped members) = 3^N, i.e. each joint configuration's weight is
+    formed and added exactly once."""
+    import re
+
+    monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
+    monkeypatch.setenv("FAMSEQ_KEEP_SRC", "1")
+    ped = fs.synthetic_pedigree(name)
+    ctx = fs.Context(fs.make_model(ped), device=-1)
+    ctx.set_option("enum_impl", 1)
+    p = ctx.plan()
+    ctx.close()
+    src = open(p["enum_lane_code_object"][:-6] + ".hip").read()
+    leaf = len(re.findall(r"^\s*(S(?:_\d)+) = __builtin_fma\(\w+, W(?:_\w+)+, \1\);", src, flags=re.M))
+    loops = len(re.findall(r"#pragma unroll 1\n\s*for \(int g\d+ = 0; g\d+ < 3; \+\+g\d+\)", src))
+    m = re.search(r"(\d+) looped \+ (\d+) unrolled members", src.splitlines()[0])
+    assert m and loops == int(m.group(1)) and int(m.group(1)) + int(m.group(2)) == ped.n
+    assert leaf == 3 ** int(m.group(2))
+    assert leaf * 3 ** loops == 3 ** ped.n
+    # the accumulators are reduced into marginals exactly once, after all loops
+    acc = set(re.findall(r"double (S(?:_\d)+) = 0;", src))
+    assert len(acc) in (9, 27) and all(src.count(a + " = 0;") == 1 for a in acc)
