@@ -1,0 +1,128 @@
+"""The generated kernels' arithmetic, checked without a GPU.
+
+The per-pedigree kernels (csrc/enum_codegen.cpp, csrc/elim_codegen.cpp) are straight-line C++ inside
+a HIP shell.  Generated for a one-lane workgroup (FAMSEQ_*_BT=1) the shell degenerates to a plain
+loop over sites, so the very same source — HIP qualifiers defined away, compiler pins and barriers
+removed — compiles with g++ and can be compared with the oracle here.  This is a test of the
+GENERATORS (indexing, tables, accumulation order, status rules); it is not a product path: nothing
+in famseq_amd/ can run this way, and the GPU parity tests remain the check of what ships.
+"""
+import ctypes as C
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import famseq_amd as fs
+from _cases import load_cases
+
+SHIM = r"""
+#include <cmath>
+struct v2d { double x, y; };
+struct idx3_ { int x; };
+static idx3_ threadIdx{0}, blockIdx{0}, gridDim{1};
+#define __global__
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __builtin_amdgcn_ballot_w64(p) ((unsigned long)(p))
+#define __builtin_amdgcn_readfirstlane(v) (v)
+"""
+
+
+def host_source(src: str) -> str:
+    src = src.replace("#include <hip/hip_runtime.h>", SHIM)
+    src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() (void)0", src)
+    src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "")
+    src = src.replace("__attribute__((address_space(3)))", "")
+    src = re.sub(r'asm volatile\(""[^\n;]*\);', "", src)  # compiler pins / fences: no arithmetic in them
+    assert "asm" not in src
+    return src
+
+
+def factor_tables(m):
+    """Tc[4 flag combos][founder male, founder female, child male, child female][27] — the block
+    csrc/bn_kernel.hip build_factor_tables uploads (family.cpp:885-893, :992-1009, :1052-1073)."""
+    tc = np.zeros((4, 4, 27))
+    for fl in range(4):
+        known, x = fl & 1, fl & 2
+        autos = np.array(m.genoProbK[:] if known else m.genoProbN[:])
+        male = np.array((m.genoProbXK[:] if known else m.genoProbXN[:])) if x else autos
+        tc[fl, 0, 0:27:9], tc[fl, 1, 0:27:9] = male, autos
+        tc[fl, 2] = m.pcp2Xm[:] if x else m.pcp2[:]
+        tc[fl, 3] = m.pcp2Xf[:] if x else m.pcp2[:]
+    return tc.reshape(-1)
+
+
+def misaligned(shape, dtype=np.float64):
+    """An array whose data pointer is 8 mod 16: the generated code then takes its 8-byte staging
+    path (the 16-byte one steps by BT / 2 lanes, which a one-lane block does not have)."""
+    n = int(np.prod(shape))
+    raw = np.zeros(n + 2, dtype=dtype)
+    off = 1 if raw.ctypes.data % 16 == 0 else 0
+    out = raw[off:off + n].reshape(shape)
+    assert out.ctypes.data % 16 == 8
+    return out
+
+
+def run_host(fn, model, lk, flags, lc=None):
+    n_sites, n = lk.shape[0], lk.shape[1]
+    a = misaligned(lk.shape)
+    a[...] = lk
+    post, single = misaligned(lk.shape), misaligned(lk.shape)
+    post[...] = -1
+    single[...] = -1
+    st = np.full(n_sites, 77, np.uint8)
+    fl = np.ascontiguousarray(flags, np.uint8)
+    tc = np.ascontiguousarray(factor_tables(model))
+    fn(a.ctypes.data, fl.ctypes.data, post.ctypes.data, single.ctypes.data, st.ctypes.data, n_sites, tc.ctypes.data,
+       float(model.lc if lc is None else lc))
+    return post, single, st
+
+
+CASES = load_cases()
+
+
+@pytest.mark.parametrize("kind", ["lane", "elim"])
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_generated_arithmetic_matches_the_fixtures(case, kind, tmp_path, monkeypatch):
+    ped = case.pedigree()
+    model = fs.make_model(ped, **case.consts)
+    probe = fs.Context(model, device=-1)
+    supported = probe.plan()["elim_supported"]
+    probe.close()
+    if kind == "elim" and not supported:
+        pytest.skip("pedigree with a loop: enumeration only")
+    fn = build_host_kernel(model, kind, tmp_path, monkeypatch)
+    post, single, st = run_host(fn, model, case.lk, case.flags)
+    assert np.array_equal(st, case.status)
+    ok = (case.status & 3) == 0
+    assert np.array_equal(single[(case.status & 3) != 1], case.single[(case.status & 3) != 1])
+    np.testing.assert_allclose(post[ok], case.post[ok], rtol=1e-12, atol=0)
+    assert np.all(np.isnan(post[~ok]))
+
+
+def build_host_kernel(model, kind, tmp_path, monkeypatch):
+    """Generate the kernel of `model` for a one-lane workgroup and compile its source for the host."""
+    cache = tmp_path / ("cache_" + kind)
+    cache.mkdir(exist_ok=True)
+    for k, v in dict(FAMSEQ_KERNEL_CACHE=str(cache), FAMSEQ_KEEP_SRC="1", FAMSEQ_LANE_BT="1", FAMSEQ_ELIM_BT="1",
+                     FAMSEQ_LANE_MINWAVES="1").items():
+        monkeypatch.setenv(k, v)
+    ctx = fs.Context(model, device=-1)
+    if kind == "lane":
+        ctx.set_option("enum_impl", 1)
+        obj, entry = ctx.plan()["enum_lane_code_object"], "famseq_enum_lane"
+    else:
+        ctx.set_option("engine", fs.ENGINE_ELIM)
+        obj, entry = ctx.plan()["elim_code_object"], "famseq_elim"
+    ctx.close()
+    src = open(obj[:-6] + ".hip").read()
+    assert "#define BT 1\n" in src
+    cpp, so = str(cache / "k.cpp"), str(cache / "k.so")
+    open(cpp, "w").write(host_source(src))
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-w", "-shared", "-fPIC", "-o", so, cpp])
+    fn = getattr(C.CDLL(so), entry)
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_double]
+    return fn
