@@ -126,3 +126,33 @@ def build_host_kernel(model, kind, tmp_path, monkeypatch):
     fn.restype = None
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_double]
     return fn
+
+
+@pytest.mark.parametrize("kind", ["lane", "elim"])
+@pytest.mark.parametrize("seed", [0, 1, 2, 5])
+def test_generated_arithmetic_on_random_pedigrees(seed, kind, tmp_path, monkeypatch):
+    """Randomly grown pedigrees (marriage loops on seed 0, unsequenced members, hard zeros, mu = 0,
+    every flag combination) against the oracle: the generators' ordering and table logic on shapes
+    no fixture has."""
+    import oracle
+    from test_gpu_random_pedigrees import grow_pedigree, random_likelihoods
+
+    rng = np.random.RandomState(1000 + seed)
+    n = int(rng.randint(3, 10))
+    ped = grow_pedigree(rng, n, allow_loops=seed % 3 == 0)
+    ped.relations()
+    mu = [1e-7, 1e-7, 1e-4, 0.0][seed % 4]
+    lk, flags = random_likelihoods(rng, ped, 48)
+    ref = oracle.OracleModel(ped.ids, ped.mids, ped.fids, ped.genders, ped.sequenced, mrate=mu).bn_batch(lk, flags, threads=4)
+    model = fs.make_model(ped, mrate=mu)
+    probe = fs.Context(model, device=-1)
+    supported = probe.plan()["elim_supported"]
+    probe.close()
+    if kind == "elim" and not supported:
+        pytest.skip("pedigree with a loop: enumeration only")
+    fn = build_host_kernel(model, kind, tmp_path, monkeypatch)
+    post, single, st = run_host(fn, model, lk, flags)
+    assert np.array_equal(st, ref[2])
+    ok, s_ok = (st & 3) == 0, (st & 3) != 1
+    assert np.array_equal(single[s_ok], ref[1][s_ok])
+    np.testing.assert_allclose(post[ok], ref[0][ok], rtol=1e-10, atol=0)
