@@ -406,6 +406,7 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
              "\",\"enum_lane_shape\":\"" + enumgen_describe(c->model) + "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + json_str(c->lane.path) +
              "\",\"enum_lane_failed\":" + std::string(c->lane_failed ? "1" : "0") + ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
              ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + ",\"elim_variant\":" + std::to_string(c->elim_variant) +
+             ",\"elim_conditioned_members\":" + std::to_string(elim_conditioned_members(c->model)) +
              ",\"elim_blocks_per_cu\":" + std::to_string(c->elim_blocks_per_cu) + ",\"enum_lane_variant\":" +
              std::to_string(c->lane_variant) + ",\"enum_lane_blocks_per_cu\":" + std::to_string(c->lane_blocks_per_cu) + "}";
   return c->json.c_str();

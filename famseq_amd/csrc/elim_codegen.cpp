@@ -9,7 +9,9 @@
 // On a loop-free pedigree (the domain of the reference's own Elston-Stewart -method 2,
 // family.cpp:1126-1403) the factor graph is a forest and two messages per edge give every
 // marginal exactly: O(27 N) flops per site instead of 2*3^N, which makes the path HBM-bound.
-// Pedigrees with marriage loops are rejected here; the enumeration engine handles them.
+// A pedigree with loops (consanguinity, marriage loops) is made a forest by conditioning on the
+// smallest set of members that cuts every cycle (up to three): their genotypes are enumerated in a
+// loop around the message passing, 3^|cut| passes per site (Emitter::conditioned_body).
 //
 // The kernel is emitted as straight-line HIP for this one topology: every index is a literal,
 // so a lane keeps a whole site (likelihoods, messages) in registers; one lane = one site.
@@ -39,8 +41,59 @@ struct Graph {
   int N = 0;
   std::vector<Family> fam;
   std::vector<std::vector<int>> nb;  // member -> adjacent families
-  std::vector<int> scaled;           // one member per connected component
+  std::vector<int> scaled;           // loop-free pedigrees: one member per connected component carries 1e7
+  // Pedigrees with loops: the members of `cut` are conditioned on (their genotypes are enumerated
+  // around the message passing), which leaves a forest.  comp[p] = component of the non-cut member p
+  // in that forest, rep[c] = one member of component c.
+  std::vector<int> cut, comp, rep;
+  bool is_cut(int p) const {
+    for (int c : cut)
+      if (c == p) return true;
+    return false;
+  }
 };
+
+// Union-find pass over the bipartite member/family graph without the members in `cut`.
+// Returns false on a cycle.  comp (optional) receives a component id per member (-1 for cut ones).
+bool forest_without(const Graph &g, const std::vector<int> &cut, std::vector<int> *comp, std::vector<int> *rep) {
+  const int nf = (int)g.fam.size();
+  std::vector<int> parent(g.N + nf);
+  std::iota(parent.begin(), parent.end(), 0);
+  std::function<int(int)> find = [&](int x) { return parent[x] == x ? x : parent[x] = find(parent[x]); };
+  auto cutm = [&](int p) {
+    for (int c : cut)
+      if (c == p) return true;
+    return false;
+  };
+  for (int f = 0; f < nf; ++f) {
+    std::vector<int> mem = {g.fam[f].mo, g.fam[f].fa};
+    mem.insert(mem.end(), g.fam[f].kids.begin(), g.fam[f].kids.end());
+    int live = 0;
+    for (int p : mem) {
+      if (cutm(p)) continue;
+      ++live;
+      const int a = find(p), b = find(g.N + f);
+      if (a == b) return false;
+      parent[a] = b;
+    }
+    if (!cut.empty() && live == 0) return false;  // a family of conditioned members only: not handled
+  }
+  if (comp) {
+    comp->assign(g.N, -1);
+    rep->clear();
+    std::map<int, int> id;
+    for (int p = 0; p < g.N; ++p) {
+      if (cutm(p)) continue;
+      const int r = find(p);
+      if (!id.count(r)) {
+        id[r] = (int)rep->size();
+        rep->push_back(p);
+      }
+      (*comp)[p] = id[r];
+    }
+  }
+  return true;
+}
 
 bool build_graph(const famseq_model &m, Graph &g, std::string *why) {
   g.N = m.n_members;
@@ -63,31 +116,29 @@ bool build_graph(const famseq_model &m, Graph &g, std::string *why) {
     g.fam[it->second].kids.push_back(i);
     g.nb[i].push_back(it->second);
   }
-  // forest check on the bipartite member/family graph
-  std::vector<int> parent(g.N + g.fam.size());
-  std::iota(parent.begin(), parent.end(), 0);
-  std::function<int(int)> find = [&](int x) { return parent[x] == x ? x : parent[x] = find(parent[x]); };
-  for (size_t f = 0; f < g.fam.size(); ++f) {
-    std::vector<int> mem = {g.fam[f].mo, g.fam[f].fa};
-    mem.insert(mem.end(), g.fam[f].kids.begin(), g.fam[f].kids.end());
-    for (int p : mem) {
-      const int a = find(p), b = find(g.N + (int)f);
-      if (a == b) {
-        if (why) *why = "the pedigree has a loop (consanguinity or marriage loop); use the enumeration engine";
-        return false;
+  if (forest_without(g, {}, &g.comp, &g.rep)) {
+    g.scaled = g.rep;  // one member per connected component
+    return true;
+  }
+  // A loop (consanguinity, marriage loop): the smallest set of members whose conditioning breaks
+  // every cycle, up to three of them (3^|cut| passes of message passing per site).
+  for (int size = 1; size <= 3; ++size) {
+    std::vector<int> pick(size);
+    std::function<bool(int, int)> search = [&](int k, int from) {
+      if (k == size) return forest_without(g, pick, &g.comp, &g.rep);
+      for (int p = from; p < g.N; ++p) {
+        pick[k] = p;
+        if (search(k + 1, p + 1)) return true;
       }
-      parent[a] = b;
+      return false;
+    };
+    if (search(0, 0)) {
+      g.cut = pick;
+      return true;
     }
   }
-  std::vector<char> seen(parent.size(), 0);
-  for (int p = 0; p < g.N; ++p) {
-    const int r = find(p);
-    if (!seen[r]) {
-      seen[r] = 1;
-      g.scaled.push_back(p);
-    }
-  }
-  return true;
+  if (why) *why = "the pedigree's loops need more than three conditioning members; use the enumeration engine";
+  return false;
 }
 
 class Emitter {
@@ -95,8 +146,71 @@ class Emitter {
   Emitter(const famseq_model &m, const Graph &g, int fences, bool scalar_t) : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t) {}
 
   std::string body() {
-    for (int p = 0; p < g_.N; ++p) marginal(p);
-    return o_.str();
+    if (g_.cut.empty()) {
+      for (int p = 0; p < g_.N; ++p) {
+        marginal(p);
+        normalise(p, "m" + num(p));
+      }
+      return o_.str();
+    }
+    return conditioned_body();
+  }
+
+  // Pedigree with loops: enumerate the genotypes of the cut members around the message passing.
+  // For one assignment a of the cut members every family sees an indicator in their place, the rest
+  // is a forest, and with  Z_c = total weight of component c,  L = 1e7 * prod_cut local(a):
+  //   member p of component c :  acc[p][g] += m_p[g] * L * prod_{c' != c} Z_c'
+  //   cut member k            :  acc[k][a_k] += L * prod_c Z_c
+  // (unnormalised marginals: the normalisation happens once, after the last assignment).
+  std::string conditioned_body() {
+    const int nc = (int)g_.cut.size(), ncomp = (int)g_.rep.size();
+    int total = 1;
+    for (int k = 0; k < nc; ++k) total *= 3;
+    std::ostringstream head;
+    for (int p = 0; p < g_.N; ++p) head << "      double acc" << p << "_0 = 0, acc" << p << "_1 = 0, acc" << p << "_2 = 0;\n";
+    head << "#pragma unroll 1\n      for (int as_ = 0; as_ < " << total << "; ++as_) {\n";
+    int div = 1;
+    for (int k = 0; k < nc; ++k) {
+      head << "      const int a" << g_.cut[k] << " = (as_ / " << div << ") % 3;\n";
+      div *= 3;
+    }
+    // local factors of the cut members at their assigned genotype, and the reference's 1e7
+    std::string lam = "10000000.0";
+    for (int k : g_.cut) {
+      const std::string c = loc(k);
+      o_ << "      const double lam" << k << " = a" << k << " == 0 ? " << c << "_0 : (a" << k << " == 1 ? " << c << "_1 : " << c
+         << "_2);\n";
+      lam = "(" + lam + " * lam" + num(k) + ")";
+    }
+    o_ << "      const double Lam = " << lam << ";\n";
+    for (int c = 0; c < ncomp; ++c) {
+      marginal(g_.rep[c]);
+      o_ << "      const double Zc" << c << " = (m" << g_.rep[c] << "_0 + m" << g_.rep[c] << "_1) + m" << g_.rep[c] << "_2;\n";
+    }
+    for (int c = 0; c < ncomp; ++c) {  // weight of everything outside component c
+      std::string w = "Lam";
+      for (int c2 = 0; c2 < ncomp; ++c2)
+        if (c2 != c) w = "(" + w + " * Zc" + num(c2) + ")";
+      o_ << "      const double Wc" << c << " = " << w << ";\n";
+    }
+    std::string all = "Lam";
+    for (int c = 0; c < ncomp; ++c) all = "(" + all + " * Zc" + num(c) + ")";
+    o_ << "      const double Wall = " << all << ";\n";
+    for (int p = 0; p < g_.N; ++p) {
+      if (g_.is_cut(p)) {
+        for (int g = 0; g < 3; ++g) o_ << "      acc" << p << "_" << g << " += a" << p << " == " << g << " ? Wall : 0.0;\n";
+        continue;
+      }
+      marginal(p);
+      for (int g = 0; g < 3; ++g)
+        o_ << "      acc" << p << "_" << g << " = __builtin_fma(m" << p << "_" << g << ", Wc" << g_.comp[p] << ", acc" << p << "_" << g
+           << ");\n";
+      fence(1);
+    }
+    std::string out = head.str() + o_.str() + "      }\n";
+    o_.str("");
+    for (int p = 0; p < g_.N; ++p) normalise(p, "acc" + num(p));
+    return out + o_.str();
   }
 
  private:
@@ -147,6 +261,12 @@ class Emitter {
   // member -> family message v{p}f{F}_g = local * prod of the other families' messages
   std::string var2fac(int p, int F) {
     const std::string n = "v" + num(p) + "f" + num(F);
+    if (g_.is_cut(p)) {  // a conditioned member: every family sees its assigned genotype, nothing flows through
+      if (once(n))
+        for (int g = 0; g < 3; ++g)
+          o_ << "      const double " << n << "_" << g << " = a" << p << " == " << g << " ? 1.0 : 0.0;\n";
+      return n;
+    }
     if (once(n)) {
       std::vector<std::string> in = {loc(p)};
       for (int F2 : g_.nb[p])
@@ -220,7 +340,9 @@ class Emitter {
     return n;
   }
 
+  // unnormalised marginal m{p}_g = local * prod of the messages of the adjacent families
   void marginal(int p) {
+    if (!once("m" + num(p))) return;
     std::vector<std::string> in = {loc(p)};
     for (int F : g_.nb[p]) in.push_back(fac2var(F, p));
     for (int g = 0; g < 3; ++g) {
@@ -228,10 +350,14 @@ class Emitter {
       for (size_t k = 0; k < in.size(); ++k) o_ << (k ? " * " : "") << in[k] << "_" << g;
       o_ << ";\n";
     }
-    o_ << "      { const double s = (m" << p << "_0 + m" << p << "_1) + m" << p << "_2; if (s <= 0) bn_fail = true;\n"
+  }
+
+  // row p of the output: `from`_g / sum, with the reference's failure rule (family.cpp:943-954)
+  void normalise(int p, const std::string &from) {
+    o_ << "      { const double s = (" << from << "_0 + " << from << "_1) + " << from << "_2; if (s <= 0) bn_fail = true;\n"
        << "        const double r = 1.0 / s;  // one division per row; this engine is not bit-ordered anyway\n"
-       << "        q[" << 3 * p << "] = m" << p << "_0 * r; q[" << 3 * p + 1 << "] = m" << p << "_1 * r; q[" << 3 * p + 2
-       << "] = m" << p << "_2 * r; }\n";
+       << "        q[" << 3 * p << "] = " << from << "_0 * r; q[" << 3 * p + 1 << "] = " << from << "_1 * r; q[" << 3 * p + 2
+       << "] = " << from << "_2 * r; }\n";
   }
 };
 
@@ -240,6 +366,11 @@ class Emitter {
 bool elim_supported(const famseq_model &m, std::string *why) {
   Graph g;
   return build_graph(m, g, why);
+}
+
+int elim_conditioned_members(const famseq_model &m) {
+  Graph g;
+  return build_graph(m, g, nullptr) ? (int)g.cut.size() : -1;
 }
 
 int elim_block_threads(const famseq_model &m) {
@@ -464,8 +595,9 @@ std::string elim_source(const famseq_model &m, int variant) {
   //         1: a fence after every family->member message, 2: also after local factors and child
   //         summaries, 3: also between the members of the single posterior
   return kernel_shell(m, "famseq_elim",
-                      "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families, variant " +
-                          std::to_string(variant),
+                      "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families" +
+                          (g.cut.empty() ? "" : ", conditioned on " + std::to_string(g.cut.size()) + " member(s)") +
+                          ", variant " + std::to_string(variant),
                       Emitter(m, g, variant < 2 ? variant : 2, /*scalar_t=*/variant >= 1).body(), bt, min_waves,
                       /*regs_l=*/false, variant >= 3, /*chrx_loop=*/variant >= 1);
 }

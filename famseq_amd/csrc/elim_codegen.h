@@ -10,6 +10,8 @@ namespace famseq {
 
 // Loop-free pedigree (member/nuclear-family graph is a forest)?  `why` receives the reason if not.
 bool elim_supported(const famseq_model &m, std::string *why);
+// members conditioned on to cut the pedigree's loops (0 for a loop-free pedigree), -1 if unsupported
+int elim_conditioned_members(const famseq_model &m);
 // HIP source of `extern "C" __global__ famseq_elim(lk, flags, post, single, status, n_sites, tc, lc)`
 // specialised for the model's topology, sexes and sequenced set.  Throws if unsupported.
 // variant 0..kElimVariants-1: decreasing instruction-level parallelism / register pressure

@@ -504,9 +504,10 @@ famseq_ctx *make_ctx(const Options &o, const Ped &ped, const vector<uint8_t> &se
     return nullptr;
   }
   // -method 2 (the reference's Elston-Stewart peeling, family.cpp:1126-1403) computes the same
-  // marginals exactly on loop-free pedigrees: here that is the sum-product engine.
+  // marginals exactly: here that is the sum-product engine (loops are handled by conditioning on up
+  // to three members).
   if (o.method == 2 && famseq_set_option(ctx, "engine", FAMSEQ_ENGINE_ELIM) != 0) {
-    std::cout << "-method 2 needs a pedigree without loops: " << famseq_last_error(ctx) << std::endl
+    std::cout << "-method 2 cannot serve this pedigree: " << famseq_last_error(ctx) << std::endl
               << "Use -method 1 for this pedigree." << std::endl;
     famseq_destroy(ctx);
     return nullptr;
@@ -1046,7 +1047,7 @@ void help() {
             << "-lkType\t\tn:normal(default); log10: log10 scaled; ln: ln scaled; PS: phred scaled." << std::endl
             << "-pedFile\tThe name of the file storing the pedigree information." << std::endl
             << "-output\t\tThe name of output file" << std::endl
-            << "-method\t\t1(default): Bayesian network enumeration; 2: exact sum-product (loop-free pedigrees)." << std::endl
+            << "-method\t\t1(default): Bayesian network enumeration; 2: exact sum-product." << std::endl
             << "-mRate\t\tMutation rate. The default value is 1e-7" << std::endl
             << "-v\t\tOnly record the position at which the genotype is not RR in the output file." << std::endl
             << "-a\t\tRecord all the position in the output file." << std::endl
@@ -1094,8 +1095,8 @@ int main(int argc, char **argv) {
     std::cout << "There are some improper parameters in the command line. Some parameters are set to default."
               << std::endl;
   if (o.method == 3) {
-    std::cout << "This build implements -method 1 (Bayesian network) and -method 2 (exact sum-product on a loop-free "
-                 "pedigree, the result of Elston-Stewart peeling); -method 3 (MCMC) is not part of it." << std::endl;
+    std::cout << "This build implements -method 1 (Bayesian network) and -method 2 (exact sum-product, "
+                 "the result of Elston-Stewart peeling); -method 3 (MCMC) is not part of it." << std::endl;
     return -1;
   }
   Ped ped;

@@ -49,7 +49,8 @@ extern "C" {
 /* engines (famseq_set_option "engine") */
 #define FAMSEQ_ENGINE_ENUM 0 /* 3^N joint-genotype enumeration: any pedigree (the reference's -method 1 algorithm) */
 #define FAMSEQ_ENGINE_ELIM 1 /* exact sum-product on the pedigree's factor graph: same marginals in O(27 N) per
-                                site; loop-free pedigrees only; kernel generated and compiled per pedigree */
+                                site (pedigrees with loops: conditioned on up to three members, x3 per member);
+                                kernel generated and compiled per pedigree */
 
 /* error codes (negative returns) */
 #define FAMSEQ_E_ARG (-1)      /* bad argument / model rejected */
@@ -114,7 +115,7 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *                   can be built, team kernel otherwise
  *   "engine"        FAMSEQ_ENGINE_ENUM (default) or FAMSEQ_ENGINE_ELIM; selecting ELIM generates the
  *                   kernel for this pedigree, compiles it with hipcc (cached on disk) and fails with
- *                   FAMSEQ_E_ARG on a pedigree with loops
+ *                   FAMSEQ_E_ARG on a pedigree whose loops need more than three conditioned members
  * Returns 0 or FAMSEQ_E_ARG. */
 int famseq_set_option(famseq_ctx *ctx, const char *key, int64_t value);
 

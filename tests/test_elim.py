@@ -27,16 +27,38 @@ def test_generated_kernel_compiles(name):
     ctx.close()
 
 
-def test_loop_pedigree_is_rejected():
+def test_loop_pedigree_is_served_by_conditioning():
+    """A first-cousin marriage closes a loop in the member/family graph: the engine conditions on
+    one member (three passes of message passing per site) instead of refusing the pedigree."""
     ped = cousins_marry()
     ped.relations()
     ctx = fs.Context(fs.make_model(ped), device=-1)
-    assert ctx.plan()["elim_supported"] == 0
-    with pytest.raises(fs.FamseqError, match="loop"):
-        ctx.set_option("engine", fs.ENGINE_ELIM)
-    assert ctx.plan()["engine"] == fs.ENGINE_ENUM  # stays on enumeration
+    assert ctx.plan()["elim_supported"] == 1 and ctx.plan()["elim_conditioned_members"] == 1
+    ctx.set_option("engine", fs.ENGINE_ELIM)
+    assert ctx.plan()["engine"] == fs.ENGINE_ELIM
     with pytest.raises(fs.FamseqError):
         ctx.set_option("engine", 7)
+    ctx.close()
+
+
+def test_too_many_loops_stay_on_enumeration():
+    """Five marriages between two sibships are four independent loops and need four conditioned
+    members: beyond the engine's limit of three, so it says so and the ctx stays on enumeration."""
+    ids, mids, fids, gen = [1, 2, 3, 4], [0, 0, 0, 0], [0, 0, 0, 0], [1, 2, 1, 2]
+    sons, daughters = [], []
+    for k in range(5):  # five sons of couple 1x2, five daughters of couple 3x4
+        ids.append(len(ids) + 1); mids.append(2); fids.append(1); gen.append(1); sons.append(ids[-1])
+        ids.append(len(ids) + 1); mids.append(4); fids.append(3); gen.append(2); daughters.append(ids[-1])
+    for fa, mo in zip(sons, daughters):
+        ids.append(len(ids) + 1); mids.append(mo); fids.append(fa); gen.append(1)
+    assert len(ids) == 19
+    ped = fs.Pedigree(ids, mids, fids, gen, ["s%d" % i for i in ids])
+    ped.relations()
+    ctx = fs.Context(fs.make_model(ped), device=-1)
+    assert ctx.plan()["elim_supported"] == 0
+    with pytest.raises(fs.FamseqError, match="conditioning"):
+        ctx.set_option("engine", fs.ENGINE_ELIM)
+    assert ctx.plan()["engine"] == fs.ENGINE_ENUM
     ctx.close()
 
 

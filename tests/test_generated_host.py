@@ -92,7 +92,7 @@ def test_generated_arithmetic_matches_the_fixtures(case, kind, tmp_path, monkeyp
     supported = probe.plan()["elim_supported"]
     probe.close()
     if kind == "elim" and not supported:
-        pytest.skip("pedigree with a loop: enumeration only")
+        pytest.skip("more loops than the sum-product engine conditions on")
     fn = build_host_kernel(model, kind, tmp_path, monkeypatch)
     post, single, st = run_host(fn, model, case.lk, case.flags)
     assert np.array_equal(st, case.status)
@@ -149,10 +149,31 @@ def test_generated_arithmetic_on_random_pedigrees(seed, kind, tmp_path, monkeypa
     supported = probe.plan()["elim_supported"]
     probe.close()
     if kind == "elim" and not supported:
-        pytest.skip("pedigree with a loop: enumeration only")
+        pytest.skip("more loops than the sum-product engine conditions on")
     fn = build_host_kernel(model, kind, tmp_path, monkeypatch)
     post, single, st = run_host(fn, model, lk, flags)
     assert np.array_equal(st, ref[2])
     ok, s_ok = (st & 3) == 0, (st & 3) != 1
     assert np.array_equal(single[s_ok], ref[1][s_ok])
+    np.testing.assert_allclose(post[ok], ref[0][ok], rtol=1e-10, atol=0)
+
+
+def test_conditioning_on_a_first_cousin_marriage(tmp_path, monkeypatch):
+    """The sum-product kernel on a pedigree with a loop (one conditioned member, three passes)
+    against the oracle's enumeration, all flag combinations."""
+    import oracle
+    from test_elim import cousins_marry
+    from test_gpu_random_pedigrees import random_likelihoods
+
+    ped = cousins_marry()
+    ped.relations()
+    rng = np.random.RandomState(7)
+    lk, flags = random_likelihoods(rng, ped, 64)
+    ref = oracle.OracleModel(ped.ids, ped.mids, ped.fids, ped.genders, ped.sequenced).bn_batch(lk, flags, threads=4)
+    model = fs.make_model(ped)
+    fn = build_host_kernel(model, "elim", tmp_path, monkeypatch)
+    post, single, st = run_host(fn, model, lk, flags)
+    assert np.array_equal(st, ref[2])
+    ok = (st & 3) == 0
+    assert ok.sum() > 20
     np.testing.assert_allclose(post[ok], ref[0][ok], rtol=1e-10, atol=0)

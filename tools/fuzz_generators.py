@@ -1,4 +1,4 @@
-"""tools/fuzz_generators.py [first_seed] [n_seeds] [max_members] — host-side fuzz of the two kernel
+"""tools/fuzz_generators.py [first_seed] [n_seeds] [max_members] [loops] — host-side fuzz of the two kernel
 generators: random pedigrees (tests/test_gpu_random_pedigrees.grow_pedigree) -> generated source for a
 one-lane workgroup -> g++ -> compare with the oracle (the machinery of tests/test_generated_host.py).
 No GPU involved; prints one line per seed and exits non-zero on the first mismatch."""
@@ -23,11 +23,12 @@ class Env:  # the little of pytest's monkeypatch that build_host_kernel uses
 
 
 first, count, max_n = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 0), (2, 20), (3, 11)))
+always_loops = len(sys.argv) > 4 and sys.argv[4] == "loops"  # every pedigree may close marriage loops
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.RandomState(5000 + seed)
     n = int(rng.randint(3, max_n + 1))
-    ped = grow_pedigree(rng, n, allow_loops=seed % 4 == 0)
+    ped = grow_pedigree(rng, n, allow_loops=always_loops or seed % 4 == 0)
     ped.relations()
     mu = [1e-7, 1e-4, 0.0][seed % 3]
     lk, flags = random_likelihoods(rng, ped, 24 if n > 9 else 48)
@@ -44,6 +45,8 @@ for seed in range(first, first + count):
         ok, s_ok = (ref[2] & 3) == 0, (ref[2] & 3) != 1
         good = np.array_equal(st, ref[2]) and np.array_equal(single[s_ok], ref[1][s_ok]) and \
             np.allclose(post[ok], ref[0][ok], rtol=1e-10, atol=0)
-        print("seed %3d n=%2d %-4s %s  (%s)" % (seed, n, kind, "ok" if good else "MISMATCH", plan["enum_lane_shape"] if kind == "lane" else "statuses %s" % sorted(set(st.tolist()))), flush=True)
+        print("seed %3d n=%2d %-4s %s  (%s)" % (seed, n, kind, "ok" if good else "MISMATCH", plan["enum_lane_shape"] if kind == "lane" else "statuses %s, %d conditioned" % (sorted(set(st.tolist())), plan["elim_conditioned_members"])), flush=True)
+    if not plan["elim_supported"]:
+        print("seed %3d n=%2d elim not supported (more than three conditioning members)" % (seed, n), flush=True)
         bad += not good
 sys.exit(1 if bad else 0)
