@@ -341,3 +341,24 @@ def test_known_and_chrx_bits_mixed_inside_every_wave(engine):
     ctx.close()
     assert np.array_equal(st, ref[2]) and np.array_equal(single, ref[1])
     np.testing.assert_allclose(post, ref[0], rtol=RTOL, atol=0)
+
+
+def test_sum_product_on_a_pedigree_with_a_loop():
+    """First-cousin marriage: the sum-product engine conditions on one member; same answer as both
+    enumeration kernels and the oracle."""
+    from test_elim import cousins_marry
+    from test_gpu_random_pedigrees import random_likelihoods
+
+    ped = cousins_marry()
+    ped.relations()
+    lk, flags = random_likelihoods(np.random.RandomState(11), ped, 300)
+    ref = oracle.OracleModel(ped.ids, ped.mids, ped.fids, ped.genders, ped.sequenced).bn_batch(lk, flags, threads=4)
+    for opt in (dict(engine=fs.ENGINE_ELIM), dict(enum_impl=1), dict(enum_impl=0)):
+        ctx = fs.Context(fs.make_model(ped), **opt)
+        if "engine" in opt:
+            assert ctx.plan()["elim_conditioned_members"] == 1
+        post, single, st = ctx.bn_batch(lk, flags)
+        ctx.close()
+        assert np.array_equal(st, ref[2]), opt
+        ok = (st & 3) == 0
+        np.testing.assert_allclose(post[ok], ref[0][ok], rtol=RTOL, atol=0, err_msg=str(opt))
