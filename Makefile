@@ -39,9 +39,12 @@ $(CLI): $(CSRC)/host/famseq_cli.cpp include/famseq_hip.h $(LIB)
 	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ $(CSRC)/host/famseq_cli.cpp -Lfamseq_amd/lib -lfamseq_hip -lpthread \
 	    -Wl,-rpath,'$$ORIGIN/../famseq_amd/lib' -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
 
-# FETCH_SIZE / WRITE_SIZE calibration micro-benchmark (profiles/r01a/calib_fetch_write.txt)
-tools/calib_fetch: tools/calib_fetch.hip
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+# measuring aids: FETCH_SIZE / WRITE_SIZE calibration, the traffic shape's
+# ceiling, sustained fp64 FMA rate, timing of hand-edited generated kernels
+TOOLS := tools/calib_fetch tools/io_ceiling tools/fp64_latency tools/kernel_bench
+tools/%: tools/%.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-unused-value -o $@ $<
+tools: $(TOOLS)
 
 oracle:
 	$(MAKE) -C oracle all $(if $(wildcard /root/reference/src/family.cpp),ref,)
@@ -49,4 +52,4 @@ oracle:
 clean:
 	rm -rf build famseq_amd/lib bin
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean tools
