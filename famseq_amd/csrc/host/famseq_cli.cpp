@@ -125,7 +125,9 @@ struct Options {
   bool lk_mode = false;
   bool pack_mode = false;  // `FamSeq pack`: vcf -> packed binary PL file (no GPU)
   bool pl_mode = false;    // `FamSeq PL`: packed binary PL file -> calls
-  string pl_file;
+  bool unpack_mode = false;  // `FamSeq unpack`: packed PL file + packed result file -> the text `FamSeq PL` writes
+  bool bin_output = false;   // `FamSeq PL -binOutput`: results as a packed result file, not as text
+  string pl_file, po_file;
   vector<string> vcf_files;
   string lk_file, ped_file, out_file, loc_file;
   bool var_only = false, all_line = false, diff_only = false, pos_order = false;
@@ -186,6 +188,10 @@ int parse_options(int argc, char **argv, Options &o) {
       }
     } else if (o.pl_mode && opt == "plFile") {
       if (!need_file(o.pl_file, "packed PL file")) return -1;
+    } else if (o.unpack_mode && opt == "poFile") {
+      if (!need_file(o.po_file, "packed result file")) return -1;
+    } else if (o.pl_mode && !o.unpack_mode && opt == "binOutput") {
+      o.bin_output = true;
     } else if (o.lk_mode && opt == "lkFile") {
       if (!need_file(o.lk_file, "likelihood file")) return -1;
     } else if (opt == "pedFile") {
@@ -276,6 +282,10 @@ int parse_options(int argc, char **argv, Options &o) {
   }
   if (o.pl_mode && o.pl_file.empty()) {
     std::cout << "The name of packed PL file must be set. Please input the file name (-plFile)." << std::endl;
+    return -1;
+  }
+  if (o.unpack_mode && o.po_file.empty()) {
+    std::cout << "The name of packed result file must be set. Please input the file name (-poFile)." << std::endl;
     return -1;
   }
   if (o.lk_mode && !o.pl_mode && o.lk_file.empty()) {
@@ -562,6 +572,12 @@ struct PackWriter {
   }
 };
 
+// Packed result file (`FamSeq PL -binOutput`), little-endian: "FSPO0001", n_seq u32, reserved u32,
+// n_sites u64, n_seq x 32-byte names; then blocks of  n u64 | status[n] u8 | gpp[n][n_seq][3] f64 |
+// fpp[n][n_seq][3] f64 | fgt[n][n_seq] i8  — exactly what famseq_bn_call_batch hands back, so that a
+// run is bounded by the host link and the disk, not by printing 6 n_seq numbers per site.
+const char kPoMagic[8] = {'F', 'S', 'P', 'O', '0', '0', '0', '1'};
+
 bool run_pl(const Options &o, const Ped &ped) {
   std::ifstream fin(o.pl_file.c_str(), std::ios::binary);
   if (!fin.is_open()) {
@@ -606,22 +622,73 @@ bool run_pl(const Options &o, const Ped &ped) {
     std::cout << "No sample of " << o.pl_file << " is in the ped file." << std::endl;
     return false;
   }
-  famseq_model m;
-  famseq_ctx *ctx = make_ctx(o, ped, sequenced, m);
-  if (!ctx) return false;
-  std::ofstream fout(o.out_file.c_str());
-  fout << "##FORMAT=<ID=GPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
-          "calculated by individual-base Method\">" << std::endl;
-  fout << "##FORMAT=<ID=FPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
-          "calculated by FamSeqPro\">" << std::endl;
-  fout << "##FORMAT=<ID=FGT,Number=1,Type=String,Description=\"Genotype called by FamSeqPro\">" << std::endl;
-  fout << "##FS mutation rate=" << o.mrate << " " << std::endl;
-  fout << "##FS genotype frequency in pupulation: "; put_triple(fout, m.genoProbN); fout << std::endl;
-  fout << "#FORMAT\t";
-  for (uint32_t c : seq_cols) fout << names[c] << '\t';
-  fout << std::endl;
+  const size_t k = seq_members.size();
 
-  const size_t cap = batch_capacity(), k = seq_members.size();
+  // unpack mode: the results come from a packed result file instead of the GPU
+  std::ifstream fpo;
+  if (o.unpack_mode) {
+    fpo.open(o.po_file.c_str(), std::ios::binary);
+    char pm[8];
+    uint32_t pk = 0, reserved = 0;
+    uint64_t pn = 0;
+    fpo.read(pm, 8);
+    fpo.read(reinterpret_cast<char *>(&pk), 4);
+    fpo.read(reinterpret_cast<char *>(&reserved), 4);
+    fpo.read(reinterpret_cast<char *>(&pn), 8);
+    if (!fpo || std::memcmp(pm, kPoMagic, 8) != 0 || pk != k) {
+      std::cout << o.po_file << " is not a packed result file for these samples." << std::endl;
+      return false;
+    }
+    for (size_t j = 0; j < k; j++) {
+      char buf[33] = {0};
+      fpo.read(buf, 32);
+      if (names[seq_cols[j]] != buf) {
+        std::cout << o.po_file << " was written for other samples than " << o.pl_file << " holds." << std::endl;
+        return false;
+      }
+    }
+  }
+
+  famseq_model m;
+  famseq_ctx *ctx = nullptr;
+  if (o.unpack_mode) {  // only the header needs the model's priors
+    if (famseq_model_init(&m, ped.n(), ped.id.data(), ped.mid.data(), ped.fid.data(), ped.gender.data(), sequenced.data(),
+                          o.mrate, o.lrc) != 0) {
+      std::cout << "Cannot initiate family. Please check ped file." << std::endl;
+      return false;
+    }
+    if (o.gN.size() == 3) std::copy(o.gN.begin(), o.gN.end(), m.genoProbN);
+  } else {
+    ctx = make_ctx(o, ped, sequenced, m);
+    if (!ctx) return false;
+  }
+  std::ofstream fout(o.out_file.c_str(), o.bin_output ? std::ios::binary : std::ios::out);
+  uint64_t written = 0;
+  if (o.bin_output) {
+    const uint32_t k32 = (uint32_t)k, reserved = 0;
+    fout.write(kPoMagic, 8);
+    fout.write(reinterpret_cast<const char *>(&k32), 4);
+    fout.write(reinterpret_cast<const char *>(&reserved), 4);
+    fout.write(reinterpret_cast<const char *>(&written), 8);
+    for (uint32_t c : seq_cols) {
+      char buf[32] = {0};
+      std::strncpy(buf, names[c].c_str(), 31);
+      fout.write(buf, 32);
+    }
+  } else {
+    fout << "##FORMAT=<ID=GPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
+            "calculated by individual-base Method\">" << std::endl;
+    fout << "##FORMAT=<ID=FPP,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled for posterior probability "
+            "calculated by FamSeqPro\">" << std::endl;
+    fout << "##FORMAT=<ID=FGT,Number=1,Type=String,Description=\"Genotype called by FamSeqPro\">" << std::endl;
+    fout << "##FS mutation rate=" << o.mrate << " " << std::endl;
+    fout << "##FS genotype frequency in pupulation: "; put_triple(fout, m.genoProbN); fout << std::endl;
+    fout << "#FORMAT\t";
+    for (uint32_t c : seq_cols) fout << names[c] << '\t';
+    fout << std::endl;
+  }
+
+  const size_t cap = batch_capacity();
   vector<char> raw(cap * rec);
   vector<uint8_t> flags(cap), status(cap);
   vector<uint16_t> pl(cap * k * 3);
@@ -629,20 +696,54 @@ bool run_pl(const Options &o, const Ped &ped) {
   vector<int8_t> fgt(cap * k);
   bool ok = true;
   while (ok) {
-    fin.read(raw.data(), (std::streamsize)raw.size());
-    const size_t n = size_t(fin.gcount()) / rec;
-    if (n == 0) break;
-    for (size_t s = 0; s < n; s++) {  // de-interleave: flags[] and the PED-matched columns of pl[]
+    size_t n = 0;
+    if (o.unpack_mode) {  // the result file's blocks set the pace
+      uint64_t bn = 0;
+      fpo.read(reinterpret_cast<char *>(&bn), 8);
+      if (!fpo || bn == 0) break;
+      if (bn > cap) {
+        raw.resize(bn * rec); flags.resize(bn); status.resize(bn); pl.resize(bn * k * 3);
+        gpp.resize(bn * k * 3); fpp.resize(bn * k * 3); fgt.resize(bn * k);
+      }
+      n = (size_t)bn;
+      fin.read(raw.data(), (std::streamsize)(n * rec));
+      fpo.read(reinterpret_cast<char *>(status.data()), (std::streamsize)n);
+      fpo.read(reinterpret_cast<char *>(gpp.data()), (std::streamsize)(n * k * 24));
+      fpo.read(reinterpret_cast<char *>(fpp.data()), (std::streamsize)(n * k * 24));
+      fpo.read(reinterpret_cast<char *>(fgt.data()), (std::streamsize)(n * k));
+      if (!fpo || size_t(fin.gcount()) != n * rec) {
+        std::cout << "The packed files end early or do not belong together." << std::endl;
+        ok = false;
+        break;
+      }
+    } else {
+      fin.read(raw.data(), (std::streamsize)(cap * rec));
+      n = size_t(fin.gcount()) / rec;
+      if (n == 0) break;
+    }
+    parallel_for(n, [&](size_t s) {  // de-interleave: flags[] and the PED-matched columns of pl[]
       const char *r = raw.data() + s * rec;
       flags[s] = uint8_t(r[0]);
       for (size_t j = 0; j < k; j++) std::memcpy(&pl[(s * k + j) * 3], r + 1 + 6 * seq_cols[j], 6);
+    });
+    if (!o.unpack_mode) {
+      const int rc = famseq_bn_call_batch(ctx, (int64_t)n, nullptr, pl.data(), flags.data(), seq_members.data(), (int32_t)k,
+                                          gpp.data(), fpp.data(), fgt.data(), status.data());
+      if (rc != 0) {
+        std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx) << std::endl;
+        ok = false;
+        break;
+      }
     }
-    const int rc = famseq_bn_call_batch(ctx, (int64_t)n, nullptr, pl.data(), flags.data(), seq_members.data(), (int32_t)k,
-                                        gpp.data(), fpp.data(), fgt.data(), status.data());
-    if (rc != 0) {
-      std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx) << std::endl;
-      ok = false;
-      break;
+    if (o.bin_output) {
+      const uint64_t bn = n;
+      fout.write(reinterpret_cast<const char *>(&bn), 8);
+      fout.write(reinterpret_cast<const char *>(status.data()), (std::streamsize)n);
+      fout.write(reinterpret_cast<const char *>(gpp.data()), (std::streamsize)(n * k * 24));
+      fout.write(reinterpret_cast<const char *>(fpp.data()), (std::streamsize)(n * k * 24));
+      fout.write(reinterpret_cast<const char *>(fgt.data()), (std::streamsize)(n * k));
+      written += n;
+      continue;
     }
     vector<string> lines(n);
     parallel_for(n, [&](size_t s) {
@@ -673,8 +774,13 @@ bool run_pl(const Options &o, const Ped &ped) {
     });
     for (size_t s = 0; s < n; s++) fout.write(lines[s].data(), (std::streamsize)lines[s].size());
   }
-  famseq_destroy(ctx);
-  return ok;
+  if (o.bin_output) {
+    fout.seekp(16);
+    fout.write(reinterpret_cast<const char *>(&written), 8);
+  }
+  fout.close();
+  if (ctx) famseq_destroy(ctx);
+  return ok && !fout.fail();
 }
 
 // ---- VCF driver ----------------------------------------------------------------------------
@@ -1058,7 +1164,9 @@ void help() {
             << "-genoProbXK\tPr(G) for chromosome X of males, in dbSNP. Default 0.5 0.5." << std::endl
             << "-LRC\t\tLikelihood ratio criterion for the single-sample shortcut. Default 1." << std::endl
             << "pack\t\tFamSeq pack -vcfFile f -pedFile p -output f.fspl: write the computable sites as packed integer PLs." << std::endl
-            << "PL\t\tFamSeq PL -plFile f.fspl -pedFile p -output o: call variants from a packed PL file." << std::endl
+            << "PL\t\tFamSeq PL -plFile f.fspl -pedFile p -output o [-binOutput]: call variants from a packed PL file" << std::endl
+            << "\t\t(-binOutput: write a packed result file instead of text)." << std::endl
+            << "unpack\t\tFamSeq unpack -plFile f.fspl -poFile r.fspo -pedFile p -output o: the text of a packed result file." << std::endl
             << "Environment: FAMSEQ_DEVICE (GPU index, default 0), FAMSEQ_BATCH (sites per GPU batch)." << std::endl;
 }
 
@@ -1074,9 +1182,9 @@ int main(int argc, char **argv) {
     help();
     return 0;
   }
-  if (mode != "vcf" && mode != "LK" && mode != "pack" && mode != "PL") {
+  if (mode != "vcf" && mode != "LK" && mode != "pack" && mode != "PL" && mode != "unpack") {
     std::cout << "Cannot recognize the input type: \"" << argv[1] << "\"." << std::endl
-              << "The input type can only be vcf or LK (or pack / PL for the packed binary PL format)" << std::endl << std::endl
+              << "The input type can only be vcf or LK (or pack / PL / unpack for the packed binary formats)" << std::endl << std::endl
               << "Type FamSeq -h for help." << std::endl;
     return -1;
   }
@@ -1086,8 +1194,9 @@ int main(int argc, char **argv) {
     return -1;
   }
   Options o;
-  o.lk_mode = mode == "LK" || mode == "PL";
-  o.pl_mode = mode == "PL";
+  o.lk_mode = mode == "LK" || mode == "PL" || mode == "unpack";
+  o.pl_mode = mode == "PL" || mode == "unpack";
+  o.unpack_mode = mode == "unpack";
   o.pack_mode = mode == "pack";
   const int rc = parse_options(argc, argv, o);
   if (rc < 0) return -1;

@@ -51,3 +51,36 @@ def read_plfile(path, mmap=True):
     else:
         data = np.fromfile(path, dtype=dt, offset=off, count=n)
     return names, data["flags"], data["pl"]
+
+
+RESULT_MAGIC = b"FSPO0001"
+
+
+def read_results(path):
+    """Packed result file written by `FamSeq PL -binOutput`:
+      0 "FSPO0001"  8 uint32 n_seq  12 uint32 reserved  16 uint64 n_sites  24 n_seq x char[32] names
+      then blocks:  uint64 n | status[n] u8 | gpp[n][n_seq][3] f64 | fpp[n][n_seq][3] f64 | fgt[n][n_seq] i8
+    -> dict(names, status[S], gpp[S,n_seq,3], fpp[S,n_seq,3], fgt[S,n_seq])."""
+    with open(path, "rb") as f:
+        head = f.read(24)
+        if head[:8] != RESULT_MAGIC:
+            raise ValueError("%s is not a packed result file" % path)
+        k = int(np.frombuffer(head[8:12], "<u4")[0])
+        total = int(np.frombuffer(head[16:24], "<u8")[0])
+        names = [f.read(32).rstrip(b"\0").decode() for _ in range(k)]
+        st, gpp, fpp, fgt = [], [], [], []
+        while True:
+            b = f.read(8)
+            if len(b) < 8:
+                break
+            n = int(np.frombuffer(b, "<u8")[0])
+            st.append(np.frombuffer(f.read(n), "u1"))
+            gpp.append(np.frombuffer(f.read(n * k * 24), "<f8").reshape(n, k, 3))
+            fpp.append(np.frombuffer(f.read(n * k * 24), "<f8").reshape(n, k, 3))
+            fgt.append(np.frombuffer(f.read(n * k), "i1").reshape(n, k))
+    out = dict(names=names, status=np.concatenate(st) if st else np.zeros(0, "u1"),
+               gpp=np.concatenate(gpp) if gpp else np.zeros((0, k, 3)), fpp=np.concatenate(fpp) if fpp else np.zeros((0, k, 3)),
+               fgt=np.concatenate(fgt) if fgt else np.zeros((0, k), "i1"))
+    if out["status"].shape[0] != total:
+        raise ValueError("%s: header says %d sites, blocks hold %d" % (path, total, out["status"].shape[0]))
+    return out

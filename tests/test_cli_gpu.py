@@ -10,6 +10,8 @@ import subprocess
 
 import pytest
 
+from famseq_amd import plfile
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -182,3 +184,23 @@ def test_packed_pl_pipeline_gives_the_vcf_results(vcf, ped, tmp_path):
             assert t1 == t2
             for u, w in zip(g1.split(",") + f1.split(","), g2.split(",") + f2.split(",")):
                 assert num_close(u, w), (x, y)
+
+
+@pytest.mark.parametrize("vcf,ped", [("test_subset.vcf", "fam01.ped"), ("probe.vcf", "probe.ped")])
+def test_binary_result_file_unpacks_to_the_same_text(vcf, ped, tmp_path):
+    """`FamSeq PL -binOutput` writes what the GPU hands back; `FamSeq unpack` turns it into the very
+    text `FamSeq PL` prints (byte for byte), without a GPU context.  Small batches: several blocks."""
+    b, txt, po, back, o = tmp_path / "x.fspl", tmp_path / "p.txt", tmp_path / "r.fspo", tmp_path / "u.txt", TD + "/" + ped
+    r = subprocess.run([CLI, "pack", "-vcfFile", TD + "/" + vcf, "-pedFile", o, "-output", str(b)], capture_output=True, text=True)
+    assert r.returncode == 0
+    env = dict(os.environ, FAMSEQ_BATCH="5")
+    for args, out in ((["PL", "-plFile", str(b), "-pedFile", o], txt),
+                      (["PL", "-plFile", str(b), "-pedFile", o, "-binOutput"], po),
+                      (["unpack", "-plFile", str(b), "-poFile", str(po), "-pedFile", o], back)):
+        p = subprocess.run([CLI] + args + ["-output", str(out)], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+    assert open(po, "rb").read(8) == b"FSPO0001"
+    assert open(back).read() == open(txt).read() and os.path.getsize(txt) > 500
+    # and the Python reader sees the same numbers
+    res = plfile.read_results(str(po))
+    assert res["status"].shape[0] == sum(1 for line in open(txt) if not line.startswith("#"))

@@ -21,4 +21,6 @@ def run(args, label):
 run(["vcf", "-vcfFile", vcf, "-pedFile", pedf, "-output", os.path.join(d, "o.vcf")], "FamSeq vcf")
 run(["pack", "-vcfFile", vcf, "-pedFile", pedf, "-output", os.path.join(d, "s.fspl")], "FamSeq pack")
 run(["PL", "-plFile", os.path.join(d, "s.fspl"), "-pedFile", pedf, "-output", os.path.join(d, "o.txt")], "FamSeq PL")
+run(["PL", "-plFile", os.path.join(d, "s.fspl"), "-pedFile", pedf, "-output", os.path.join(d, "o.fspo"), "-binOutput"], "PL -binOutput")
+print("packed results: %.1f MB" % (os.path.getsize(os.path.join(d, "o.fspo")) / 1e6))
 print("packed file: %.1f MB" % (os.path.getsize(os.path.join(d, "s.fspl")) / 1e6))
