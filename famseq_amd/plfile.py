@@ -84,3 +84,25 @@ def read_results(path):
     if out["status"].shape[0] != total:
         raise ValueError("%s: header says %d sites, blocks hold %d" % (path, total, out["status"].shape[0]))
     return out
+
+
+def write_results(path, names, status, gpp, fpp, fgt, block=65536):
+    """The writer side of read_results (what `FamSeq PL -binOutput` produces), in blocks of `block` sites."""
+    k, s = len(names), len(status)
+    gpp = np.ascontiguousarray(gpp, "<f8").reshape(s, k, 3)
+    fpp = np.ascontiguousarray(fpp, "<f8").reshape(s, k, 3)
+    fgt = np.ascontiguousarray(fgt, "i1").reshape(s, k)
+    status = np.ascontiguousarray(status, "u1")
+    with open(path, "wb") as f:
+        f.write(RESULT_MAGIC)
+        f.write(np.array([k, 0], "<u4").tobytes())
+        f.write(np.array([s], "<u8").tobytes())
+        for n in names:
+            f.write(n.encode()[:31].ljust(32, b"\0"))
+        for lo in range(0, s, block):
+            hi = min(s, lo + block)
+            f.write(np.array([hi - lo], "<u8").tobytes())
+            f.write(status[lo:hi].tobytes())
+            f.write(gpp[lo:hi].tobytes())
+            f.write(fpp[lo:hi].tobytes())
+            f.write(fgt[lo:hi].tobytes())

@@ -4,6 +4,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 
 from famseq_amd import plfile
 from famseq_amd.pedigree import read_ped
@@ -84,3 +85,24 @@ def test_python_writer_roundtrip(tmp_path):
         n, f, p = plfile.read_plfile(path, mmap=mm)
         assert n == ["s0", "s1", "s2", "s3", "s4"] and np.array_equal(f, flags) and np.array_equal(p, pl)
     assert os.path.getsize(path) == 24 + 5 * 32 + 1000 * 31
+
+
+def test_packed_result_file_round_trip(tmp_path):
+    from famseq_amd import plfile
+
+    rng = np.random.RandomState(3)
+    s, k = 1000, 4
+    st = rng.randint(0, 3, s).astype(np.uint8)
+    gpp, fpp = rng.rand(s, k, 3) * 200, rng.rand(s, k, 3) * 200
+    fgt = rng.randint(-1, 3, (s, k)).astype(np.int8)
+    path = str(tmp_path / "r.fspo")
+    plfile.write_results(path, ["a", "b", "c", "d"], st, gpp, fpp, fgt, block=300)  # 4 blocks, the last short
+    r = plfile.read_results(path)
+    assert r["names"] == ["a", "b", "c", "d"]
+    assert np.array_equal(r["status"], st) and np.array_equal(r["fgt"], fgt)
+    assert np.array_equal(r["gpp"], gpp) and np.array_equal(r["fpp"], fpp)
+    with open(path, "r+b") as f:  # a header that promises more sites than the blocks hold
+        f.seek(16)
+        f.write(np.array([s + 1], "<u8").tobytes())
+    with pytest.raises(ValueError):
+        plfile.read_results(path)
