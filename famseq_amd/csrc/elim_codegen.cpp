@@ -388,8 +388,10 @@ int elim_block_threads(const famseq_model &m) {
 //                   BEFORE the single posterior takes over the row.
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
-                         bool chrx_loop) {
-  const int N = m.n_members, W3 = 3 * N, ROW = W3 | 1;
+                         bool chrx_loop, int row_doubles) {
+  // ROW: the lane's LDS row, W3 doubles padded to an odd count (conflict-free ds_read_b64); a
+  // generator may ask for more (spare slots it uses itself), odd again
+  const int N = m.n_members, W3 = 3 * N, ROW = (row_doubles > 0 ? row_doubles : W3) | 1;
   // Prefetching the next chunk costs W3 doubles of registers next to the W3 marginals; on MI355X it
   // pays while it does not spill (ped5: +14 %); beyond the limits below it spills and loses.
   int prefetch_max_n = regs_l ? 7 : 10;  // the register-resident shell already holds the row: less room

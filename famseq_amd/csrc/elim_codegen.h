@@ -23,7 +23,7 @@ int elim_block_threads(const famseq_model &m);
 // Shared shell of the generated kernels (see elim_codegen.cpp).
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
-                         bool chrx_loop = false);
+                         bool chrx_loop = false, int row_doubles = 0);
 
 }  // namespace famseq
 #endif

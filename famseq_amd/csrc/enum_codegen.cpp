@@ -108,7 +108,7 @@ Shape choose_shape(const famseq_model &m, int cap) {
 
 class Gen {
  public:
-  Gen(const famseq_model &m, const Shape &s) : m_(m), s_(s), nu_((int)s.unrolled.size()), outer_(s.outer) {}
+  Gen(const famseq_model &m, const Shape &s, int row_len) : m_(m), s_(s), nu_((int)s.unrolled.size()), row_len_(row_len), outer_(s.outer) {}
 
   // The per-step tables are plain expressions of the loop digits, so the compiler hoists each one
   // to the outermost loop whose digit it mentions.  Put the member whose digit feeds the most
@@ -150,7 +150,7 @@ class Gen {
     compute_deps();
     choose_superleaf();
     order_outer_loops();
-    const int no = (int)outer_.size(), row_len = (3 * s_.N) | 1;
+    const int no = (int)outer_.size(), row_len = row_len_;
     l_in_lds_ = 6 * no <= row_len;
     o_ << "      // outer (looped) members:";
     for (int p : outer_) o_ << " " << p;
@@ -234,6 +234,7 @@ class Gen {
   const famseq_model &m_;
   const Shape &s_;
   const int nu_;
+  const int row_len_;  // doubles in the lane's LDS row (>= 3N, odd)
   std::vector<int> outer_;  // looped members, outermost first
   std::ostringstream o_;
   int uid_ = 0;
@@ -581,13 +582,27 @@ std::string enumgen_source(const famseq_model &m, int variant) {
   const Shape s = choose_shape(m, cap);
   if (s.unrolled.empty()) throw std::runtime_error("enumeration codegen: empty unrolled set");
   const int bt = enumgen_block_threads(m);
+  // The lane's LDS row: 3N doubles padded to an odd count, plus — while two workgroups per CU still
+  // fit in the 160 KB — room for the likelihoods of unrolled members whose tables are rebuilt inside
+  // the loops (otherwise re-read from global memory there: L2 misses that show up as HBM traffic).
+  int row_len = (3 * m.n_members) | 1;
+  {
+    int looped_tables = 0;  // unrolled members with a looped parent
+    for (int p : s.unrolled)
+      if (m.mother[p] >= 0 && (s.upos[m.mother[p]] < 0 || s.upos[m.father[p]] < 0)) ++looped_tables;
+    const int used = 6 * (int)s.outer.size() <= row_len ? 6 * (int)s.outer.size() : 3 * (int)s.outer.size();
+    const int want = (used + 3 * looped_tables) | 1;
+    const int fit = ((160 * 1024 / 2 - 432 * 8) / (bt * 8) - 1) | 1;  // odd, two workgroups per CU
+    if (want > row_len) row_len = std::min(want, std::max(row_len, fit));
+  }
   std::string what = "3^N enumeration, lane per site, " + std::to_string(s.outer.size()) + " looped + " +
                      std::to_string(s.unrolled.size()) + " unrolled members, variant " + std::to_string(variant);
   int min_waves = bt / 128;
   if (const char *e = std::getenv("FAMSEQ_LANE_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
   // regs_l: LDS-resident likelihoods measured 17% slower.  variant 0: the members of the single
   // posterior overlap, 1: fenced one from the other (fewer registers)
-  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s).body(), bt, min_waves, /*regs_l=*/true, variant >= 1);
+  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s, row_len).body(), bt, min_waves, /*regs_l=*/true, variant >= 1,
+                      /*chrx_loop=*/false, row_len);
 }
 
 }  // namespace famseq
