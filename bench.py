@@ -337,7 +337,10 @@ def main():
                          "kernel": kernel_name, "kernel_ms": kernel_ms,
                          "bytes_per_site": bytes_per_site,
                          "read_GBps": S * (24 * n + 1) / (kernel_ms * 1e-3) / 1e9,
-                         "frac_of_measured_copy_6290GBps": achieved / 6290.0},
+                         "frac_of_measured_copy_6290GBps": achieved / 6290.0,
+                         "note": ("a 3^N enumeration is bound by the fp64 vector ALU for N >= 7 (arithmetic intensity 3^N/24 "
+                                  "flop/B): see fp64_valu; the same marginals by sum-product are HBM-bound: see elim_engine")
+                         if n >= 7 and a.engine == "enum" else None},
             "fp64_valu": {"achieved": S * ops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TOPS,
                           "unit": "T fp64 FMA/s (one per joint configuration)",
                           "frac": S * ops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
