@@ -474,7 +474,6 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  const long per_wg = (chunks + gridDim.x - 1) / gridDim.x;\n"
     << "  const long c_lo = (long)blockIdx.x * per_wg, c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;\n"
     << "  const double kNaN = __builtin_nan(\"\");\n"
-    << "  const bool lc_is_one = lc == 1.0;\n"
     << "  double *row = s_io + tid * ROW;\n"
     // (regs_l = false) volatile forces a fresh LDS read per use.  The address space is spelled out:
     // hipcc does not infer it for volatile accesses and would emit flat_load instead of ds_read.
@@ -516,12 +515,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
         s << "      row[" << 3 * p << "] = p0 / s; row[" << 3 * p + 1 << "] = p1 / s; row[" << 3 * p + 2 << "] = p2 / s;\n";
       if (flags_pass && m.sequenced[p])
         s << "      double big = 0; if (big < a0) big = a0; if (big < a1) big = a1; if (big < a2) big = a2;\n"
-          // family.cpp:780-786 votes with big / sum < lc.  At the default lc = 1 and a positive finite
-          // sum that is big < sum exactly (big <= pred(sum) gives a quotient <= 1 - 2^-53, which rounds
-          // below 1; big >= sum gives >= 1): the division is left to other cut-offs and to garbage input.
-          << "      const double sum = (a0 + a1) + a2;\n"
-          << "      if (lc_is_one && sum > 0 && sum < __builtin_inf()) { if (big < sum) full = true; }\n"
-          << "      else { big = big / sum; if (big < lc) full = true; }\n";
+          << "      const double sum = (a0 + a1) + a2; big = big / sum; if (big < lc) full = true;\n";
       // fence: one member at a time (interleaved division sequences would spill)
       s << "    }\n";
       if (fence_single) s << "    asm volatile(\"\" ::: \"memory\");\n";
