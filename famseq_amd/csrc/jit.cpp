@@ -139,6 +139,10 @@ std::string jit_compile(const std::string &source, int *scratch_bytes) {
   return obj;
 }
 
+// A couple of spilled registers cost less than the next variant's lost overlap (measured: 12 B of
+// scratch on the fence-free 5-member sum-product kernel, still 7 % faster than the fenced one).
+constexpr int kSpillTolerance = 16;  // bytes per lane
+
 std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked) {
   std::string best;
   int best_scratch = -1, best_i = 0;
@@ -154,7 +158,7 @@ std::string jit_pick_variant(const std::function<std::string(int)> &generate, in
       best_scratch = scratch;
       best_i = v;
     }
-    if (best_scratch == 0) break;
+    if (best_scratch <= kSpillTolerance) break;
   }
   if (picked) *picked = best_i;
   return best;

@@ -30,7 +30,7 @@ JitKernel jit_load(const std::string &source, const std::string &entry);
 std::string jit_compile(const std::string &source, int *scratch_bytes = nullptr);
 // The generators can trade instruction-level parallelism against register pressure
 // (`variant` 0 = most parallel).  Compiles variants in order and returns the source of the
-// first one that does not spill, or of the one that spills least.  *picked = its index.
+// first one that does not spill (more than 16 bytes per lane), or of the one that spills least.  *picked = its index.
 std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked = nullptr);
 void jit_unload(JitKernel &k);
 
