@@ -31,7 +31,7 @@ build/stub/libamdhip64.so:
 $(LIB): $(OBJS) build/stub/libamdhip64.so
 	@mkdir -p famseq_amd/lib
 	g++ -shared -fPIC -o $@ $(OBJS) -Wl,--no-as-needed -Lbuild/stub -lamdhip64 -Wl,--as-needed \
-	    -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags -ldl
+	    -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags -ldl -lpthread
 
 # FamSeq-compatible command line (host C++ only; talks to the GPU through the C ABI)
 $(CLI): $(CSRC)/host/famseq_cli.cpp include/famseq_hip.h $(LIB)

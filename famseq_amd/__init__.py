@@ -56,7 +56,8 @@ class CModel(C.Structure):
 ABI_SYMBOLS = [
     "famseq_transmission_tables", "famseq_model_init", "famseq_device_count", "famseq_create",
     "famseq_destroy", "famseq_last_error", "famseq_set_option", "famseq_plan_json",
-    "famseq_bn_batch", "famseq_bn_batch_device", "famseq_bn_call_batch", "famseq_call_genotypes",
+    "famseq_bn_batch", "famseq_bn_batch_sharded", "famseq_bn_batch_device", "famseq_bn_call_batch",
+    "famseq_call_genotypes",
 ]
 PL_MISSING = 0xFFFF
 
@@ -99,6 +100,8 @@ def lib():
     L.famseq_plan_json.restype = C.c_char_p
     L.famseq_bn_batch.argtypes = [C.c_void_p, C.c_int64, dp, bp, dp, dp, bp]
     L.famseq_bn_batch.restype = C.c_int
+    L.famseq_bn_batch_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, dp, bp, dp, dp, bp]
+    L.famseq_bn_batch_sharded.restype = C.c_int
     vp = C.c_void_p
     L.famseq_bn_batch_device.argtypes = [C.c_void_p, C.c_int64, vp, vp, vp, vp, vp, vp]
     L.famseq_bn_batch_device.restype = C.c_int
@@ -224,6 +227,23 @@ class Context:
         rc = lib().famseq_bn_batch_device(self._h, int(n_sites), d_lk, d_flags or None, d_post, d_single or None,
                                           d_status or None, stream or None)
         self._check(rc, "famseq_bn_batch_device")
+
+
+def bn_batch_sharded(contexts, lk, flags=None):
+    """famseq_bn_batch over several contexts (one per GPU) from this process: contiguous site ranges,
+    one host thread per context.  -> (post, single, status)."""
+    n = contexts[0].n
+    lk = np.ascontiguousarray(lk, dtype=np.float64).reshape(-1, n, 3)
+    s = lk.shape[0]
+    fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
+    post, single, status = np.empty_like(lk), np.empty_like(lk), np.zeros(s, np.uint8)
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = lib().famseq_bn_batch_sharded(arr, len(contexts), s, _p(lk, C.c_double), None if fl is None else _p(fl, C.c_uint8),
+                                       _p(post, C.c_double), _p(single, C.c_double), _p(status, C.c_uint8))
+    if rc != 0:
+        msgs = [lib().famseq_last_error(c._h).decode() for c in contexts]
+        raise FamseqError("famseq_bn_batch_sharded failed (%d): %s" % (rc, "; ".join(m for m in msgs if m)))
+    return post, single, status
 
 
 def call_genotypes(post):

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bn_kernel.h"
@@ -565,6 +566,27 @@ extern "C" int famseq_bn_batch(famseq_ctx *c, int64_t n_sites, const double *lk,
   HostIO io;
   io.lk = lk; io.flags = flags; io.post = post; io.single = post_single; io.status = status;
   return run_host(c, n_sites, io, 0);
+}
+
+extern "C" int famseq_bn_batch_sharded(famseq_ctx *const *ctxs, int n_ctx, int64_t n_sites, const double *lk,
+                                       const uint8_t *flags, double *post, double *post_single, uint8_t *status) {
+  if (!ctxs || n_ctx < 1) return FAMSEQ_E_ARG;
+  for (int g = 0; g < n_ctx; ++g)
+    if (!ctxs[g] || ctxs[g]->plan.N != ctxs[0]->plan.N) return FAMSEQ_E_ARG;
+  if (n_sites < 0 || (n_sites > 0 && (!lk || !post))) return fail(ctxs[0], FAMSEQ_E_ARG, "bad batch arguments");
+  const int64_t w = int64_t(3) * ctxs[0]->plan.N;
+  std::vector<int> rc(n_ctx, 0);
+  std::vector<std::thread> pool;
+  for (int g = 0; g < n_ctx; ++g)
+    pool.emplace_back([&, g] {
+      const int64_t lo = n_sites * g / n_ctx, hi = n_sites * (g + 1) / n_ctx;
+      rc[g] = famseq_bn_batch(ctxs[g], hi - lo, lk + lo * w, flags ? flags + lo : nullptr, post + lo * w,
+                              post_single ? post_single + lo * w : nullptr, status ? status + lo : nullptr);
+    });
+  for (std::thread &t : pool) t.join();
+  for (int g = 0; g < n_ctx; ++g)
+    if (rc[g] != 0) return rc[g];
+  return 0;
 }
 
 extern "C" int famseq_bn_call_batch(famseq_ctx *c, int64_t n_sites, const double *lk, const uint16_t *pl16,

@@ -124,12 +124,21 @@ const char *famseq_plan_json(famseq_ctx *ctx);
 
 /* ---- the operator ---------------------------------------------------------- */
 
-/* Host buffers (pageable or pinned).  Blocking.  Works in chunks on two HIP streams so that the
- * H2D / D2H copies of one chunk overlap the kernel of the other.  post_single and status may be
- * NULL.  Returns 0 or a negative error.  (The host link bounds this entry point: 722 B/site at
- * N = 10; see famseq_bn_call_batch for the compact path.) */
+/* Host buffers (pageable, or pinned for the full rate of the link).  Blocking.  Works in chunks
+ * through three event-chained stages (copy in / compute / copy out, one HIP stream each) so that both
+ * directions of the host link are busy at once.  post_single and status may be NULL.  Returns 0 or a
+ * negative error.  (The host link bounds this entry point: 722 B/site at N = 10; see
+ * famseq_bn_call_batch for the compact path.) */
 int famseq_bn_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, const uint8_t *flags,
                     double *post, double *post_single, uint8_t *status);
+
+/* The same over several GPUs of one node from one process: ctxs[g] (one per device, created by the
+ * caller for the same model) gets the contiguous site range [g*S/G, (g+1)*S/G) and its own host
+ * thread; results land in the caller's arrays in site order.  No collective: sites are independent
+ * (family.cpp:791 zeroes all state per site).  Returns 0, or the first error any
+ * ctx reported (famseq_last_error on that ctx has the text). */
+int famseq_bn_batch_sharded(famseq_ctx *const *ctxs, int n_ctx, int64_t n_sites, const double *lk, const uint8_t *flags,
+                            double *post, double *post_single, uint8_t *status);
 
 /* Device buffers already resident in HBM on ctx's device.  Enqueues on `stream`
  * (a hipStream_t; NULL = the default stream) and returns without synchronising.

@@ -362,3 +362,25 @@ def test_sum_product_on_a_pedigree_with_a_loop():
         assert np.array_equal(st, ref[2]), opt
         ok = (st & 3) == 0
         np.testing.assert_allclose(post[ok], ref[0][ok], rtol=RTOL, atol=0, err_msg=str(opt))
+
+
+def test_sharded_entry_point_over_two_contexts():
+    """famseq_bn_batch_sharded: contiguous site ranges over several contexts, one host thread each
+    (two contexts on the one GPU of this box), same bits as a single call; errors come back."""
+    c = BY["bn_synth:ped10"]
+    model = fs.make_model(c.pedigree())
+    lk = np.tile(c.lk, (40, 1, 1))[:1501]
+    flags = np.tile(c.flags, 40)[:1501]
+    one = fs.Context(model)
+    ref = one.bn_batch(lk, flags)
+    one.close()
+    ctxs = [fs.Context(model), fs.Context(model), fs.Context(model)]
+    got = fs.bn_batch_sharded(ctxs, lk, flags)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b, equal_nan=True)
+    empty = fs.bn_batch_sharded(ctxs, lk[:0], flags[:0])
+    assert empty[0].shape[0] == 0
+    for x in ctxs:
+        x.close()
+    with pytest.raises(fs.FamseqError, match="no CPU path"):
+        fs.bn_batch_sharded([fs.Context(model, device=-1)], lk[:4], flags[:4])
