@@ -27,6 +27,7 @@ static idx3_ threadIdx{0}, blockIdx{0}, gridDim{1};
 #define __launch_bounds__(...)
 #define __builtin_amdgcn_ballot_w64(p) ((unsigned long)(p))
 #define __builtin_amdgcn_readfirstlane(v) (v)
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 """
 
 
