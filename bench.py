@@ -166,7 +166,8 @@ def side_config(fs, torch, dev, stream, workload, steps, warmup):
     ctx.close()
     return {"workload": "BASELINE.json %s: %s, %d seeded synthetic sites, %d-member pedigree (3^%d = %d configs/site)"
                         % (CONFIG_OF[workload], workload, S, n, n, 3 ** n),
-            "value": S * steps / elapsed, "unit": "sites/s", "ms_per_step": elapsed / steps * 1e3, "outputs_valid": ok,
+            "value": S * steps / elapsed, "unit": "sites/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "outputs_valid": ok,
             "roofline": {"bound": "hbm", "achieved": S * bps / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": S * bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": k_ms, "bytes_per_site": bps,
                          "kernel": "famseq_enum_lane" if plan["enum_lane_code_object"] else "bn_enum_kernel<%d>" % plan["L"]}}
