@@ -10,8 +10,12 @@
 //   * the last <= 6 members in descent order ("unrolled" set U, closed under children) form a
 //     fully unrolled block of 3^|U| configurations whose factor tables (indexed by the unrolled
 //     parents' digits) are rebuilt in registers once per outer step;
-//   * inside the block prefix products are shared level by level, the deepest member's marginal
-//     takes one FMA per configuration, and every other member receives block sums.
+//   * inside the block prefix products are shared level by level; the deepest 2-3 levels (the
+//     "super-leaf") are multiplied once per outer step into a table W, and every configuration
+//     costs exactly one FMA, prefix * W[c] into the accumulator of its super-leaf digits c; those
+//     3^sl accumulators run over the whole site and are summed into the super-leaf members'
+//     marginals at the end; the other unrolled members receive block sums (Q) per prefix, the
+//     looped ones block totals kept in the lane's LDS row.
 // The generic team-per-site kernel remains the fallback (small batches, no compiler at run time).
 #include "enum_codegen.h"
 
