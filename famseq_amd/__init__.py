@@ -17,7 +17,7 @@ import sys
 
 import numpy as np
 
-from . import synth  # noqa: F401
+from . import shard, synth  # noqa: F401
 from .pedigree import Pedigree, read_ped, synthetic_pedigree  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
