@@ -48,7 +48,8 @@ struct famseq_ctx {
   int lane_blocks_per_cu = 0;
   bool lane_failed = false;
   std::string lane_error;
-  int64_t lane_min_sites = 32768;  // below this the lane kernel cannot fill 256 CUs x 4 SIMDs; the team kernel is faster
+  int64_t lane_min_sites = 14336;  // measured crossover on ped10: the lane kernel takes one chunk time (0.17 ms) for anything
+                                   // up to 64 sites per SIMD; the team kernel needs 0.18 ms from about 14 k sites on
   // device constants
   uint32_t *d_img = nullptr;
   double *d_tc = nullptr;

@@ -111,7 +111,7 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *   "enum_impl"     which enumeration kernel serves FAMSEQ_ENGINE_ENUM: 0 = the team-per-site kernel
  *                   compiled into the library (any batch size, any pedigree); 1 = the lane-per-site
  *                   kernel generated and compiled for this pedigree (fastest on large batches);
- *                   -1 (default) = lane kernel for batches of >= "lane_min_sites" (32768) sites when it
+ *                   -1 (default) = lane kernel for batches of >= "lane_min_sites" (14336) sites when it
  *                   can be built, team kernel otherwise
  *   "engine"        FAMSEQ_ENGINE_ENUM (default) or FAMSEQ_ENGINE_ELIM; selecting ELIM generates the
  *                   kernel for this pedigree, compiles it with hipcc (cached on disk) and fails with
