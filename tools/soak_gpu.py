@@ -46,5 +46,35 @@ for seed in range(first, first + count):
         if not good:
             print("seed %d n=%d sites=%d: %s" % (seed, n, n_sites, res), flush=True)
             sys.exit(1)
+    # the fused call path on the same pedigree: packed integer PLs (with missing samples, a PL beyond
+    # the table, a shuffled column order) against the fp64 entry point fed with the host's table
+    seq = np.nonzero(ped.sequenced)[0].astype(np.int32)
+    rng.shuffle(seq)
+    k = len(seq)
+    pl = rng.randint(0, 400, size=(n_sites, k, 3)).astype(np.uint16)
+    pl[np.arange(n_sites)[:, None], np.arange(k)[None, :], rng.randint(0, 3, size=(n_sites, k))] = 0
+    pl[rng.rand(n_sites, k) < 0.05] = fs.PL_MISSING
+    pl[rng.rand(n_sites, k, 3) < 0.01] = 5000
+    table = np.append(10.0 ** (-np.arange(4096) / 10.0), 0.0)
+    import math
+    table[:4096] = [math.pow(10.0, -i / 10.0) for i in range(4096)]
+    lk2 = np.ones((n_sites, n, 3))
+    for j, mbr in enumerate(seq):
+        v = table[np.minimum(pl[:, j].astype(np.int64), 4096)]
+        v[np.all(pl[:, j] == fs.PL_MISSING, axis=1)] = 1.0
+        lk2[:, mbr] = v
+    for name, opt in engines[1:]:
+        ctx = fs.Context(model, **opt)
+        a = ctx.bn_call_batch(seq, lk=lk2, flags=flags)
+        b = ctx.bn_call_batch(seq, pl16=pl, flags=flags)
+        post2, single2, st2 = ctx.bn_batch(lk2, flags)
+        ctx.close()
+        good = all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b)) and np.array_equal(a[3], st2)
+        okc = (st2 & 3) == 0
+        good = good and np.array_equal(a[2][okc], fs.call_genotypes(post2[okc][:, seq]).reshape(-1, k))
+        res.append("call/%s %s" % (name, "ok" if good else "MISMATCH"))
+        if not good:
+            print("seed %d n=%d sites=%d: %s" % (seed, n, n_sites, res), flush=True)
+            sys.exit(1)
     print("seed %3d n=%2d sites=%5d cond=%d  %s  [%.0f s]" % (seed, n, n_sites, plan["elim_conditioned_members"], ", ".join(res),
                                                           time.time() - t_start), flush=True)
