@@ -129,7 +129,22 @@ def cpu_baseline(ped, cfg, seconds, n):
 
     n1, t1 = timed(1, min(3.0, seconds / 4))
     na, ta = timed(cores, seconds)
-    return {"value": na / ta, "unit": "sites/s", "cores": cores, "kind": "port",
+    # the reference's own family.cpp (oracle/_ref, compiled in the build container from the sources
+    # where they lie; it travels as a binary), one thread, ~2 s: what the port is a port of
+    ref = None
+    try:
+        rf = oracle.RefFamily(ped.ids, ped.mids, ped.fids, ped.genders)
+        k = max(1, min(100000, int(2.0 / (per_site * 3.0)) or 1))  # the reference is ~3x slower than the port
+        lkr, flr = synth.gen_batch(mo, fa, k, cfg)
+        t0 = time.perf_counter()
+        rp = rf.bn_batch(lkr, flr)
+        tr = time.perf_counter() - t0
+        same = bool(np.array_equal(rp[0], o.bn_batch(lkr, flr, threads=1)[0]))
+        ref = {"one_core_sites_per_s": k / tr, "sample": "%d sites in %.2f s through oracle/_ref/libfamseq_ref.so "
+               "(one ctypes call per site)" % (k, tr), "bit_identical_to_port": same}
+    except Exception as e:  # noqa: BLE001 — the compiled reference is optional
+        ref = {"unavailable": str(e).splitlines()[0][:120]}
+    return {"value": na / ta, "unit": "sites/s", "cores": cores, "kind": "port", "reference": ref,
             "sample": "%d seeded %s sites (same generator as the GPU batch) on %d pthreads in %.1f s; "
                       "1 thread: %d sites in %.1f s" % (na, ped_name(ped), cores, ta, n1, t1),
             "one_core_sites_per_s": n1 / t1, "configs_per_s_per_core": n1 / t1 * 3 ** n}
