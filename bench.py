@@ -2,7 +2,9 @@
 """bench.py — variant sites/s of the pedigree BN posterior on MI355X.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ped10|ped5|ped15] [--sites S]
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 either way: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+  the process is one of the ranks; started as a plain command, bench.py launches those N ranks itself
+  (as child processes, before anything here has touched the GPU) and relays rank 0's line.
 
 A "step" is one pass of the hot path (famseq_bn_batch_device: single posterior, shortcut
 vote, 3^N enumeration, normalisation, status) over this rank's resident batch of seeded
@@ -30,7 +32,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {  # name -> (BASELINE.json config number, default sites per GPU)
     "ped5": (1, 1_000_000),
     "ped10": (2, 10_000_000),
-    "ped15": (4, 131_072),
+    "ped15": (4, 1_000_000),
     # not BASELINE configurations: the shapes most real callers have (seed numbers 5 and 6 of the same generator)
     "trio": (5, 8_000_000),
     "quad": (6, 8_000_000),
@@ -150,10 +152,11 @@ def cpu_baseline(ped, cfg, seconds, n):
             "one_core_sites_per_s": n1 / t1, "configs_per_s_per_core": n1 / t1 * 3 ** n}
 
 
-def side_config(fs, torch, dev, stream, workload, steps, warmup):
+def side_config(fs, torch, dev, stream, workload, steps, warmup, sites=0):
     """A second BASELINE configuration measured in the same process (same contract: resident
     inputs, HIP events on the launch stream), reported as a sub-object of the headline line."""
     cfg, S = WORKLOADS[workload]
+    S = sites or S
     ped = fs.synthetic_pedigree(workload)
     n = ped.n
     mo, fa = ped.relations()
@@ -188,7 +191,31 @@ def side_config(fs, torch, dev, stream, workload, steps, warmup):
             "ms_per_step": elapsed / steps * 1e3, "outputs_valid": ok,
             "roofline": {"bound": "hbm", "achieved": S * bps / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": S * bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": k_ms, "bytes_per_site": bps,
-                         "kernel": "famseq_enum_lane" if plan["enum_lane_code_object"] else "bn_enum_kernel<%d>" % plan["L"]}}
+                         "kernel": "famseq_enum_lane" if plan["enum_lane_code_object"] else "bn_enum_kernel<%d>" % plan["L"]},
+            "fp64_valu_frac": S * 3 ** n / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS}
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children of this
+    process (which has not initialised the GPU and never will), one per GPU, and pass their exit code
+    on.  Rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()  # does not initialise the GPU
+    if have < a.gpus and not a.share_gpu:
+        sys.exit("bench.py: --gpus %d but %d GPU(s) visible (use --share-gpu to rehearse the rank logic on fewer)"
+                 % (a.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def ped_name(ped):
@@ -207,12 +234,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
-            sys.exit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (a.gpus, a.gpus))
+            sys.exit(self_launch(a))
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libfamseq_hip.so has no CPU path")
     if a.share_gpu:
         local = 0
+        if a.backend == "nccl" and world > 1:
+            a.backend = "gloo"  # RCCL refuses two ranks on one device; the data path has no collective anyway
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     red_dev = dev if a.backend == "nccl" else torch.device("cpu")
@@ -293,6 +322,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+    rank_kernel_ms = [kernel_ms]
+    if world > 1:  # every rank's own mean kernel time, for the spread across GPUs
+        t = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        t[rank] = kernel_ms
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_kernel_ms = [float(x) for x in t.tolist()]
 
     # sanity on the timed outputs: generator guarantees full enumeration everywhere
     bad = int(((status & 3 if a.lc != 1.0 else status) != 0).sum().item())  # --lc experiments shortcut sites (0x80)
@@ -330,13 +365,23 @@ def main():
         bytes_per_site = (24 * n + 1) + 24 * n + 24 * n + 1
         achieved = S * bytes_per_site / (kernel_ms * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % a.workload)
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("sites_per_launch"):
-                traffic = tj["bytes_per_launch"] * S / tj["sites_per_launch"]
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_%s%s.json" % (a.workload, "_elim" if a.engine == "elim" else ""))
         ops = fp64_ops_per_site(plan, n)
         plan = ctx.plan()  # after the run: tells which enumeration kernel served the batch
+        # HBM bytes per launch from the PMC passes (tools/traffic.sh; rocprofv3 cannot wrap the driver's own
+        # run).  The file is stamped with the content hash of the code object it was measured on — the
+        # name of the generated kernel's .hsaco — and is quoted only while this run used that same code.
+        traffic_note = "no counter run on file for this workload"
+        code_hash = os.path.basename(plan["elim_code_object"] if a.engine == "elim" else plan["enum_lane_code_object"]).split(".")[0]
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("sites_per_launch") and tj.get("kernel_hash") and tj["kernel_hash"] == code_hash:
+                traffic = tj["bytes_per_launch"] * S / tj["sites_per_launch"]
+                traffic_note = "PMC FETCH_SIZE x2 + WRITE_SIZE at %d sites per launch, scaled by sites (%s), kernel %s" % (
+                    tj["sites_per_launch"], tj.get("round", "?"), code_hash)
+            else:
+                traffic_note = "the kernel has changed since the counter run on file (%s, kernel %s; this run: %s)" % (
+                    tj.get("round", "?"), tj.get("kernel_hash", "unstamped"), code_hash)
         if a.engine == "elim":
             kernel_name = "famseq_elim (generated per pedigree)"
         elif plan["enum_lane_code_object"] and not plan["enum_lane_failed"] and plan["enum_impl"] != 0:
@@ -352,12 +397,13 @@ def main():
                                    "(3^%d = %d configs/site), -method 1 BN posterior, every site takes the full enumeration"
                                    % (CONFIG_OF[a.workload], a.workload, S, n, n, 3 ** n),
                        "sites_per_gpu": S, "global_sites": total_sites, "parallelism": "sites sharded x%d, no collective" % world,
-                       "barrier_backend": (a.backend if world > 1 else None),
+                       "barrier_backend": ((a.backend + (" (ranks share one GPU: RCCL refuses duplicate devices)"
+                                                         if a.share_gpu else "")) if world > 1 else None),
                        "engine": a.engine, "lane_kernel_tiling": plan.get("enum_lane_shape"),
                        "team_kernel_plan": {k: plan[k] for k in ("L", "A", "J", "team_lanes", "teams_per_block", "block_threads",
                                                                  "lds_bytes", "blocks_per_cu")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": kernel_name, "kernel_ms": kernel_ms,
                          "bytes_per_site": bytes_per_site,
                          "read_GBps": S * (24 * n + 1) / (kernel_ms * 1e-3) / 1e9,
@@ -375,6 +421,7 @@ def main():
                           "x_over_naive_valu_bound": S / (kernel_ms * 1e-3) / (FP64_VALU_PEAK_TOPS * 1e12 / (2 * n * 3 ** n)),
                           "sustained_2_waves_per_simd": "32.9 T/s measured on a pure FMA stream (tools/fp64_latency.hip)"},
         }
+        out["per_rank_kernel_ms"] = {"min": min(rank_kernel_ms), "max": max(rank_kernel_ms), "all": rank_kernel_ms}
         if a.lc != 1.0:  # an experiment, not the BASELINE workload: say so where the judge reads the workload
             out["config"]["workload"] = "EXPERIMENT -LRC %g (sites below the cut-off skip the BN posterior); " % a.lc \
                 + out["config"]["workload"]
@@ -384,6 +431,13 @@ def main():
         if a.workload == "ped10" and world == 1 and a.engine == "enum" and not a.no_side_configs:
             # a 0.1 ms launch: K = 5 is too few to time it, and the extra steps cost nothing
             out["configs_1_ped5"] = side_config(fs, torch, dev, stream, "ped5", max(a.steps, 20), max(a.warmup, 5))
+            # at BASELINE's 1 M sites the 120 MB of input stay in the 256 MB Infinity Cache from step to step;
+            # the same kernel on 8 M sites (2.9 GB per step) is the pure HBM-streaming figure
+            big = side_config(fs, torch, dev, stream, "ped5", max(a.steps, 20), max(a.warmup, 5), sites=8_000_000)
+            out["configs_1_ped5"]["roofline"]["streaming_frac"] = big["roofline"]["frac"]
+            out["configs_1_ped5"]["roofline"]["streaming_note"] = "same kernel, 8 M sites: inputs no longer fit the Infinity Cache"
+            # BASELINE configs[4] at its full size on this one GPU (0.5 s per launch: two timed steps)
+            out["configs_4_ped15"] = side_config(fs, torch, dev, stream, "ped15", 2, 1)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ped, cfg, a.cpu_seconds, n)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]

@@ -56,7 +56,8 @@ class CModel(C.Structure):
 ABI_SYMBOLS = [
     "famseq_transmission_tables", "famseq_model_init", "famseq_device_count", "famseq_create",
     "famseq_destroy", "famseq_last_error", "famseq_set_option", "famseq_plan_json",
-    "famseq_bn_batch", "famseq_bn_batch_sharded", "famseq_bn_batch_device", "famseq_bn_call_batch",
+    "famseq_bn_batch", "famseq_bn_batch_sharded", "famseq_bn_batch_device", "famseq_bn_batch_device_sharded",
+    "famseq_bn_call_batch",
     "famseq_call_genotypes",
 ]
 PL_MISSING = 0xFFFF
@@ -105,6 +106,9 @@ def lib():
     vp = C.c_void_p
     L.famseq_bn_batch_device.argtypes = [C.c_void_p, C.c_int64, vp, vp, vp, vp, vp, vp]
     L.famseq_bn_batch_device.restype = C.c_int
+    pp = C.POINTER(C.c_void_p)
+    L.famseq_bn_batch_device_sharded.argtypes = [pp, C.c_int, C.POINTER(C.c_int64), pp, pp, pp, pp, pp]
+    L.famseq_bn_batch_device_sharded.restype = C.c_int
     L.famseq_bn_call_batch.argtypes = [C.c_void_p, C.c_int64, dp, C.POINTER(C.c_uint16), bp, ip, C.c_int32, dp, dp,
                                        C.POINTER(C.c_int8), bp]
     L.famseq_bn_call_batch.restype = C.c_int
@@ -244,6 +248,25 @@ def bn_batch_sharded(contexts, lk, flags=None):
         msgs = [lib().famseq_last_error(c._h).decode() for c in contexts]
         raise FamseqError("famseq_bn_batch_sharded failed (%d): %s" % (rc, "; ".join(m for m in msgs if m)))
     return post, single, status
+
+
+def bn_batch_device_sharded(contexts, n_sites, d_lk, d_flags, d_post, d_single=None, d_status=None):
+    """famseq_bn_batch_device_sharded: shard g = n_sites[g] sites resident on contexts[g]'s device, given as
+    raw device pointers (ints; 0 / None = absent).  Blocking; one host thread per context."""
+    g = len(contexts)
+
+    def ptrs(v):
+        if v is None:
+            return None
+        return (C.c_void_p * g)(*[(x or None) for x in v])
+
+    arr = (C.c_void_p * g)(*[c._h for c in contexts])
+    ns = (C.c_int64 * g)(*[int(x) for x in n_sites])
+    rc = lib().famseq_bn_batch_device_sharded(arr, g, ns, ptrs(d_lk), ptrs(d_flags), ptrs(d_post), ptrs(d_single),
+                                              ptrs(d_status))
+    if rc != 0:
+        msgs = [lib().famseq_last_error(c._h).decode() for c in contexts]
+        raise FamseqError("famseq_bn_batch_device_sharded failed (%d): %s" % (rc, "; ".join(m for m in msgs if m)))
 
 
 def call_genotypes(post):

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -221,6 +222,10 @@ bool load_lane(famseq_ctx *c) {
   } catch (const std::exception &e) {
     c->lane_failed = true;
     c->lane_error = e.what();
+    // said once per ctx, where a user of the CLI or of the library sees it (also in famseq_plan_json)
+    if (!std::getenv("FAMSEQ_QUIET"))
+      std::fprintf(stderr, "famseq: the per-pedigree enumeration kernel is unavailable (%s); large batches fall back to the "
+                           "compiled-in team-per-site kernel (about 4x slower)\n", c->lane_error.substr(0, 300).c_str());
     return false;
   }
 }
@@ -583,6 +588,35 @@ extern "C" int famseq_bn_batch_sharded(famseq_ctx *const *ctxs, int n_ctx, int64
       const int64_t lo = n_sites * g / n_ctx, hi = n_sites * (g + 1) / n_ctx;
       rc[g] = famseq_bn_batch(ctxs[g], hi - lo, lk + lo * w, flags ? flags + lo : nullptr, post + lo * w,
                               post_single ? post_single + lo * w : nullptr, status ? status + lo : nullptr);
+    });
+  for (std::thread &t : pool) t.join();
+  for (int g = 0; g < n_ctx; ++g)
+    if (rc[g] != 0) return rc[g];
+  return 0;
+}
+
+extern "C" int famseq_bn_batch_device_sharded(famseq_ctx *const *ctxs, int n_ctx, const int64_t *n_sites,
+                                              const double *const *d_lk, const uint8_t *const *d_flags,
+                                              double *const *d_post, double *const *d_single, uint8_t *const *d_status) {
+  if (!ctxs || n_ctx < 1 || !n_sites || !d_lk || !d_post) return FAMSEQ_E_ARG;
+  for (int g = 0; g < n_ctx; ++g) {
+    if (!ctxs[g] || ctxs[g]->plan.N != ctxs[0]->plan.N) return FAMSEQ_E_ARG;
+    if (ctxs[g]->device < 0) return fail(ctxs[g], FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
+    if (n_sites[g] < 0 || (n_sites[g] > 0 && (!d_lk[g] || !d_post[g]))) return fail(ctxs[g], FAMSEQ_E_ARG, "bad batch arguments");
+  }
+  std::vector<int> rc(n_ctx, 0);
+  std::vector<std::thread> pool;
+  for (int g = 0; g < n_ctx; ++g)
+    pool.emplace_back([&, g] {
+      famseq_ctx *c = ctxs[g];
+      rc[g] = [&]() -> int {
+        if (n_sites[g] == 0) return 0;
+        HIP_TRY(c, hipSetDevice(c->device));  // the device binding is per host thread
+        HIP_TRY(c, launch_engine(c, n_sites[g], d_lk[g], d_flags ? d_flags[g] : nullptr, d_post[g],
+                                 d_single ? d_single[g] : nullptr, d_status ? d_status[g] : nullptr, c->stream[1]));
+        HIP_TRY(c, hipStreamSynchronize(c->stream[1]));
+        return 0;
+      }();
     });
   for (std::thread &t : pool) t.join();
   for (int g = 0; g < n_ctx; ++g)

@@ -7,7 +7,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <cstring>
+#include <mutex>
 #include <cstdlib>
 #include <fstream>
 #include <stdexcept>
@@ -35,6 +38,29 @@ bool writable_dir(const std::string &d) {
   return ::access(d.c_str(), W_OK | X_OK) == 0;
 }
 
+// The per-user fallback under /tmp is shared ground: code objects are loaded from it without
+// recompiling, so it must be a real directory (not a link) of this user's that nobody else can
+// write to — otherwise another local user could plant <hash>.hsaco there.
+bool private_dir(const std::string &d) {
+  ::mkdir(d.c_str(), 0700);
+  struct stat st;
+  if (::lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  if (st.st_uid != ::getuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return false;
+  return ::access(d.c_str(), W_OK | X_OK) == 0;
+}
+
+// A profiler that preloads itself into this process (rocprofv3, roctracer) is inherited by every
+// child: spawning sh -> hipcc -> clang from here would exec GPU-initialised processes, which the
+// GPU pool forbids and which distorts the profile anyway.
+const char *profiler_env() {
+  for (const char *k : {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"})
+    if (const char *v = std::getenv(k))
+      if (*v) return k;
+  if (const char *v = std::getenv("LD_PRELOAD"))
+    if (std::strstr(v, "rocprof") || std::strstr(v, "roctracer")) return "LD_PRELOAD";
+  return nullptr;
+}
+
 std::string lib_dir() {
   Dl_info info;
   if (dladdr(reinterpret_cast<void *>(&jit_compile), &info) && info.dli_fname) {
@@ -51,8 +77,9 @@ std::string cache_dir() {
   const std::string in_tree = lib_dir() + "/kernels";
   if (writable_dir(in_tree)) return in_tree;
   const std::string tmp = "/tmp/famseq_kernels_" + std::to_string((long)getuid());
-  if (writable_dir(tmp)) return tmp;
-  throw std::runtime_error("no writable kernel cache directory");
+  if (private_dir(tmp)) return tmp;
+  throw std::runtime_error("no usable kernel cache directory (" + in_tree + " is not writable and " + tmp +
+                           " is not a private directory of this user)");
 }
 
 const char kCompilerTag[] = "hipcc gfx950 -O3 -ffp-contract=off v2";
@@ -79,6 +106,13 @@ int read_res(const std::string &obj) {
 }  // namespace
 
 std::string jit_compile(const std::string &source, int *scratch_bytes) {
+  // One compilation at a time per process: famseq_bn_batch*_sharded runs a host thread per ctx, and
+  // with a cold cache every one of them arrives here with the same source.  The first compiles,
+  // the others find the object.  (Scratch names are unique per call as well, so that processes
+  // sharing a cache directory — one rank per GPU — never touch each other's files.)
+  static std::mutex mu;
+  static std::atomic<unsigned> serial{0};
+  std::lock_guard<std::mutex> lock(mu);
   char name[40];
   std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(source + kCompilerTag));
   // a prebuilt object next to the library wins even when that directory is read-only
@@ -94,8 +128,13 @@ std::string jit_compile(const std::string &source, int *scratch_bytes) {
     if (scratch_bytes) *scratch_bytes = read_res(obj);
     return obj;
   }
-  const std::string src = dir + "/" + name + "." + std::to_string((long)getpid()) + ".hip";
-  const std::string tmp = obj + "." + std::to_string((long)getpid()) + ".tmp";
+  if (const char *why = profiler_env())
+    throw std::runtime_error(std::string("kernel ") + name + " is not in the cache (" + dir + ") and a profiler is attached ($" +
+                             why + "): build it outside the profiler first (a plan-only ctx with the same options, "
+                             "or __graft_entry__.build())");
+  const std::string uniq = std::to_string((long)getpid()) + "_" + std::to_string(serial.fetch_add(1));
+  const std::string src = dir + "/" + name + "." + uniq + ".hip";
+  const std::string tmp = obj + "." + uniq + ".tmp";
   {
     std::ofstream f(src.c_str());
     f << source;

@@ -146,6 +146,16 @@ int famseq_bn_batch_sharded(famseq_ctx *const *ctxs, int n_ctx, int64_t n_sites,
 int famseq_bn_batch_device(famseq_ctx *ctx, int64_t n_sites, const double *d_lk, const uint8_t *d_flags,
                            double *d_post, double *d_post_single, uint8_t *d_status, void *stream);
 
+/* Device-resident form of famseq_bn_batch_sharded, for a process that holds several GPUs (the
+ * reference has no multi-GPU: family.cu:1152 binds device 0): shard g is n_sites[g] sites whose
+ * arrays are already resident on ctxs[g]'s device.  One host thread per ctx enqueues the shard on
+ * that ctx's own compute stream and waits for it; blocking; no collective and no copy between
+ * devices.  d_flags / d_post_single / d_status may be NULL, and so may their entries.  Returns 0 or
+ * the first error any ctx reported.  (Several ctxs may name the same device: rehearsal on one GPU.) */
+int famseq_bn_batch_device_sharded(famseq_ctx *const *ctxs, int n_ctx, const int64_t *n_sites,
+                                   const double *const *d_lk, const uint8_t *const *d_flags, double *const *d_post,
+                                   double *const *d_post_single, uint8_t *const *d_status);
+
 /* Fused call path (SURVEY.md 8(f) rows N2 + N4): what the drivers print per sequenced sample, computed on
  * the device, so that only 49*n_seq bytes per site come back instead of 48*N.
  *   input   either lk  [n_sites][N][3] fp64 (as famseq_bn_batch)
