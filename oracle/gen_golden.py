@@ -172,6 +172,23 @@ def main():
     full = OUT + "/ref_cli/full_fam01_v.vcf"
     subprocess.check_call([oracle.REF_CLI, "vcf", "-vcfFile", REF + "/TestData/test.vcf", "-pedFile",
                            OUT + "/testdata/fam01.ped", "-output", full, "-method", "1", "-v"], stdout=subprocess.DEVNULL)
+    # BASELINE config #1 at full length: the whole TestData/test.vcf (a data file of the reference's
+    # own tests, 2 MB, kept gzipped) and the reference CLI's plain (9,749 lines) and -a (10,008 lines)
+    # outputs for fam01 — pins the header echo / one-line-lag logic and the echo / drop rules
+    # (file.cpp:143-196, :362-555) over every line, not 1 in 97 of them
+    import gzip
+
+    def gz(src, dst):
+        with open(src, "rb") as f, open(dst, "wb") as raw, gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as g:
+            shutil.copyfileobj(f, g)
+
+    gz(REF + "/TestData/test.vcf", OUT + "/testdata/test_full.vcf.gz")
+    for tag, extra in (("plain", []), ("a", ["-a"])):
+        tmp = "/tmp/famseq_full_%s.vcf" % tag
+        subprocess.check_call([oracle.REF_CLI, "vcf", "-vcfFile", REF + "/TestData/test.vcf", "-pedFile",
+                               OUT + "/testdata/fam01.ped", "-output", tmp, "-method", "1"] + extra, stdout=subprocess.DEVNULL)
+        gz(tmp, "%s/ref_cli/full_fam01_%s.vcf.gz" % (OUT, tag))
+        os.unlink(tmp)
 
     # ---- probe inputs for the CLI surface: chrX, Known, failures,
     # missing sample, GL, multi-base REF, chrY/MT/odd contigs, location file, custom flags

@@ -80,6 +80,29 @@ def test_baseline_config_1_result_lines(tmp_path):
     assert assert_same_output(out, REF + "/full_fam01_v.vcf") == 12
 
 
+@pytest.mark.parametrize("tag,extra,n_lines", [("plain", [], 9749), ("a", ["-a"], 10008)])
+@pytest.mark.parametrize("batch", [None, "7", "1000"])
+def test_baseline_config_1_full_length(tag, extra, n_lines, batch, tmp_path):
+    """BASELINE config #1 over the WHOLE TestData/test.vcf (kept gzipped as a fixture), without -v:
+    the header echo with its one-line lag, the echo / drop / all-missing / no-PL rules
+    (file.cpp:143-196, :362-555) and the order-preserving block writer over ~10 k lines.  Line counts
+    are SURVEY.md App. E's.  With FAMSEQ_BATCH=7 (parser blocks and GPU flushes of 7 lines) echo
+    lines and sites straddle hundreds of block boundaries; the default keeps it in one block."""
+    import gzip
+    import shutil
+
+    vcf, ref, out = tmp_path / "test.vcf", tmp_path / "ref.vcf", tmp_path / "o.vcf"
+    for src, dst in ((TD + "/test_full.vcf.gz", vcf), ("%s/full_fam01_%s.vcf.gz" % (REF, tag), ref)):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    env = dict(os.environ) if batch is None else dict(os.environ, FAMSEQ_BATCH=batch)
+    p = subprocess.run([CLI, "vcf", "-vcfFile", str(vcf), "-pedFile", TD + "/fam01.ped", "-method", "1", "-output", str(out)] + extra,
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert sum(1 for _ in open(ref)) == n_lines
+    assert assert_same_output(out, ref) == 12
+
+
 @pytest.mark.parametrize("fam", range(1, 7))
 def test_testdata_lk(fam, tmp_path):
     out = tmp_path / "o.txt"

@@ -64,9 +64,7 @@ def test_sharded_threads_on_a_cold_kernel_cache(tmp_path, monkeypatch, capfd):
     context must end up on the generated lane kernel, with the right answer."""
     monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
     c, lk, flags = _ped10_batch(1800)
-    # a pedigree of its own so that nothing for it is in any cache: ped10 with two genders swapped
-    ped = c.pedigree()
-    model = fs.make_model(ped)
+    model = fs.make_model(c.pedigree())
     ref_ctx = fs.Context(model, enum_impl=0)
     ref = ref_ctx.bn_batch(lk, flags)
     ref_ctx.close()
@@ -130,7 +128,7 @@ def _nccl_worker(rank, world, port, n_sites, out):
     lo, hi = fs.shard.site_range(n_sites, rank, world)
     lk, fl = fs.synth.gen_batch_torch(mo.tolist(), fa.tolist(), hi - lo, 1, first_site=lo, device=dev)
     post = torch.empty_like(lk)
-    ctx = fs.Context(fs.make_model(ped), device=rank)
+    ctx = fs.Context(fs.make_model(ped), device=rank, enum_impl=1)  # one kernel on both sides: same bits
     ctx.bn_batch_device(hi - lo, lk.data_ptr(), fl.data_ptr(), post.data_ptr(), 0, 0, torch.cuda.current_stream().cuda_stream)
     full = fs.shard.gather_sites(post, n_sites)  # RCCL all_gather on the device tensors
     t = fs.shard.max_over_ranks(1.0 + rank, device=dev)
@@ -156,7 +154,7 @@ def _run_gather(world, tmp_path):
     ped = fs.synthetic_pedigree("ped5")
     mo, fa = ped.relations()
     lk, fl = fs.synth.gen_batch(mo, fa, n_sites, 1)
-    ctx = fs.Context(fs.make_model(ped))
+    ctx = fs.Context(fs.make_model(ped), enum_impl=1)
     ref = ctx.bn_batch(lk, fl)[0]
     ctx.close()
     assert np.array_equal(np.load(out), ref)

@@ -5,53 +5,10 @@ import pytest
 
 import famseq_amd as fs
 import oracle
+from famseq_amd.synth import grow_pedigree, random_likelihoods
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-9
-
-
-def grow_pedigree(rng, n, allow_loops):
-    """Start from founders, keep adding children of random (female, male) couples; without
-    allow_loops a couple is only formed if it does not close a loop in the member/family graph."""
-    ids, mids, fids, gen = [1, 2], [0, 0], [0, 0], [1, 2]
-    comp = {1: 1, 2: 2}  # connected component of each member (for loop avoidance)
-    couples = {}
-    while len(ids) < n:
-        r = rng.rand()
-        females = [i for i, g in zip(ids, gen) if g == 2]
-        males = [i for i, g in zip(ids, gen) if g == 1]
-        if r < 0.3 or not females or not males:
-            new = len(ids) + 1
-            ids.append(new); mids.append(0); fids.append(0); gen.append(int(rng.randint(1, 3)))
-            comp[new] = new
-            continue
-        mo, fa = int(rng.choice(females)), int(rng.choice(males))
-        if (mo, fa) not in couples:
-            if not allow_loops and comp[mo] == comp[fa]:
-                continue
-            couples[(mo, fa)] = True
-            old = comp[fa]
-            for k in comp:
-                if comp[k] == old:
-                    comp[k] = comp[mo]
-        new = len(ids) + 1
-        ids.append(new); mids.append(mo); fids.append(fa); gen.append(int(rng.randint(1, 3)))
-        comp[new] = comp[mo]
-    names = ["s%d" % i if rng.rand() < 0.75 else "NA" for i in ids]
-    if all(x == "NA" for x in names):
-        names[-1] = "s_last"
-    return fs.Pedigree(ids, mids, fids, gen, names)
-
-
-def random_likelihoods(rng, ped, n_sites):
-    pl = rng.randint(0, 300, size=(n_sites, ped.n, 3)).astype(float)
-    pl[np.arange(n_sites)[:, None], np.arange(ped.n)[None, :], rng.randint(0, 3, size=(n_sites, ped.n))] = 0
-    lk = 10.0 ** (-pl / 10.0)
-    lk[rng.rand(n_sites, ped.n, 3) < 0.02] = 0.0           # hard zeros
-    sharp = rng.rand(n_sites) < 0.15                        # some sites take the -LRC shortcut
-    lk[sharp] = np.where(pl[sharp] == 0, 1.0, 1e-40)
-    lk[:, ped.sequenced == 0, :] = 1.0
-    return lk, rng.randint(0, 4, n_sites).astype(np.uint8)
 
 
 @pytest.mark.parametrize("seed", range(10))
