@@ -46,10 +46,27 @@ tools/%: tools/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-unused-value -o $@ $<
 tools: $(TOOLS)
 
+# Sanitizer recipe: the library's HOST code — model, plan, both kernel generators, the
+# JIT and the C ABI — rebuilt by g++ under AddressSanitizer + UBSan and driven on plan-only contexts by
+# tests/asan_host_check.cpp.  CPU only (GPU AddressSanitizer is not available on the pool); the two
+# kernel translation units are linked as they are (their host side is launch glue).  `make asan` builds
+# and runs it; tests/test_abi.py runs it as part of the CPU suite.
+ASAN_SRCS := capi.cpp plan.cpp model.cpp jit.cpp elim_codegen.cpp enum_codegen.cpp
+ASAN_OBJS := $(patsubst %,build/asan/%.o,$(ASAN_SRCS))
+ASAN_FLAGS := -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer \
+              -ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -I$(CSRC) -Wall -Wno-unused-result
+build/asan/%.o: $(CSRC)/% $(wildcard $(CSRC)/*.h) include/famseq_hip.h
+	@mkdir -p build/asan
+	g++ $(ASAN_FLAGS) -c $< -o $@
+build/asan/host_check: tests/asan_host_check.cpp $(ASAN_OBJS) build/bn_kernel.hip.o build/io_kernels.hip.o
+	g++ $(ASAN_FLAGS) -o $@ $^ -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -ldl -lpthread
+asan: build/asan/host_check
+	ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 ./build/asan/host_check
+
 oracle:
 	$(MAKE) -C oracle all $(if $(wildcard /root/reference/src/family.cpp),ref,)
 
 clean:
 	rm -rf build famseq_amd/lib bin
 
-.PHONY: all oracle clean tools
+.PHONY: all oracle clean tools asan

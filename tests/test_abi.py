@@ -101,3 +101,14 @@ def test_fails_loudly_without_gpu():
     m = fs.make_model(fs.synthetic_pedigree("ped5"))
     with pytest.raises(fs.FamseqError, match="no usable HIP device"):
         fs.Context(m, device=0)
+
+
+def test_host_code_is_clean_under_asan_and_ubsan():
+    """`make asan` (SURVEY.md section 5's sanitizer recipe): model, plan, both generators, the JIT and the C
+    ABI rebuilt under AddressSanitizer + UBSan and driven on plan-only contexts over eight pedigrees of
+    1-20 members, the rejections and the no-compiler path.  CPU only."""
+    import subprocess
+
+    r = subprocess.run(["make", "-s", "-C", ROOT, "asan"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "asan_host_check: ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
