@@ -45,12 +45,17 @@ struct famseq_ctx {
   // enumeration engine: the team-per-site kernel is compiled into the library; the lane-per-site
   // kernel is generated per pedigree.  enum_impl: -1 auto (lane for large batches), 0 team, 1 lane
   int enum_impl = -1;
-  JitKernel lane{};
+  JitKernel lane{};  // one lane per site (large batches)
   int lane_blocks_per_cu = 0;
   bool lane_failed = false;
   std::string lane_error;
-  int64_t lane_min_sites = 14336;  // measured crossover on ped10: the lane kernel takes one chunk time (0.17 ms) for anything
-                                   // up to 64 sites per SIMD; the team kernel needs 0.18 ms from about 14 k sites on
+  // lanes-per-site mode of the same generator for batches too small to give every lane of the chip a
+  // site: grp[d] lets 3^d lanes share a site (d = 1..4 of the outermost looped members' digits on
+  // lanes).  Compiled on first use of each d.  group_digits: -1 auto (by batch size), 0..4 forced.
+  JitKernel grp[kEnumMaxGroupDigits + 1]{};
+  int grp_blocks_per_cu[kEnumMaxGroupDigits + 1] = {};
+  int group_digits = -1, last_group_digits = 0;
+  int64_t lane_min_sites = 1024;  // below this the compiled-in team kernel answers at once (no per-pedigree compile for tiny calls)
   // device constants
   uint32_t *d_img = nullptr;
   double *d_tc = nullptr;
@@ -202,22 +207,27 @@ int load_elim(famseq_ctx *c) {
 
 // Generate/compile/load the lane-per-site enumeration kernel (once).  Returns false when it is
 // unavailable (no compiler at run time, ...): the compiled-in team kernel then serves all batches.
-bool load_lane(famseq_ctx *c) {
-  if (c->lane.fn) return true;
+// d > 0: the lanes-per-site form with 3^d lanes per site.
+bool load_lane(famseq_ctx *c, int d = 0) {
+  JitKernel &k = d == 0 ? c->lane : c->grp[d];
+  if (k.fn) return true;
   if (c->lane_failed) return false;
+  if (c->device < 0 && !k.path.empty()) return true;
   try {
     const famseq_model &mdl = c->model;
-    const std::string src = jit_pick_variant([&mdl](int v) { return enumgen_source(mdl, v); }, kEnumVariants, &c->lane_variant);
+    int variant = -1;
+    const std::string src = jit_pick_variant([&mdl, d](int v) { return enumgen_source(mdl, v, d); }, kEnumVariants, &variant);
+    if (d == 0) c->lane_variant = variant;
     if (c->device < 0) {
-      c->lane.path = jit_compile(src);
+      k.path = jit_compile(src);
       return true;
     }
     if (hipSetDevice(c->device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-    c->lane = jit_load(src, "famseq_enum_lane");
+    k = jit_load(src, "famseq_enum_lane");
     int nb = 0;
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, c->lane.fn, enumgen_block_threads(c->model), 0) != hipSuccess)
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, enumgen_block_threads(c->model), 0) != hipSuccess)
       nb = 1;
-    c->lane_blocks_per_cu = nb > 0 ? nb : 1;
+    (d == 0 ? c->lane_blocks_per_cu : c->grp_blocks_per_cu[d]) = nb > 0 ? nb : 1;
     return true;
   } catch (const std::exception &e) {
     c->lane_failed = true;
@@ -230,10 +240,31 @@ bool load_lane(famseq_ctx *c) {
   }
 }
 
+// How many of the outermost looped members' digits go on lanes for a batch of n_sites: the d that
+// minimises rounds(d) / 3^d, where a round is one lane-kernel chunk time and the chip holds
+// n_cus * 512 lanes (two waves per SIMD) per round; ties go to the smaller group.
+int pick_group_digits(const famseq_ctx *c, int64_t n_sites) {
+  const int dmax = enumgen_max_group_digits(c->model);
+  if (c->group_digits >= 0) return std::min(c->group_digits, dmax);
+  const double lanes = double(std::max(1, c->n_cus)) * 512.0;
+  int best = 0;
+  double best_t = 0;
+  for (int d = 0, g = 1; d <= dmax; ++d, g *= 3) {
+    const double rounds = std::ceil(double(n_sites) * g / lanes);
+    const double t = rounds / g + (d ? 0.002 * g : 0.0);  // + the group's reduction, a little per lane
+    if (d == 0 || t < best_t * 0.95) {
+      best = d;
+      best_t = t;
+    }
+  }
+  return best;
+}
+
 hipError_t launch_generated(famseq_ctx *c, hipFunction_t fn, int bt, int blocks_per_cu, int64_t n_sites,
                             const double *d_lk, const uint8_t *d_flags, double *d_post, double *d_single,
-                            uint8_t *d_status, hipStream_t stream) {
-  const int64_t chunks = (n_sites + bt - 1) / bt;
+                            uint8_t *d_status, hipStream_t stream, int sites_per_chunk = 0) {
+  const int spc = sites_per_chunk > 0 ? sites_per_chunk : bt;
+  const int64_t chunks = (n_sites + spc - 1) / spc;
   int64_t resident = c->grid_override > 0 ? c->grid_override : int64_t(c->n_cus) * blocks_per_cu;
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min(chunks, resident));
   long ns = (long)n_sites;
@@ -253,9 +284,17 @@ hipError_t launch_engine(famseq_ctx *c, int64_t n_sites, const double *d_lk, con
                          double *d_single, uint8_t *d_status, hipStream_t stream) {
   if (c->engine == FAMSEQ_ENGINE_ELIM) return launch_elim(c, n_sites, d_lk, d_flags, d_post, d_single, d_status, stream);
   const bool want_lane = c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites);
-  if (want_lane && load_lane(c))
-    return launch_generated(c, c->lane.fn, enumgen_block_threads(c->model), c->lane_blocks_per_cu, n_sites, d_lk, d_flags,
-                            d_post, d_single, d_status, stream);
+  if (want_lane) {
+    const int d = pick_group_digits(c, n_sites);
+    if (load_lane(c, d)) {
+      c->last_group_digits = d;
+      if (d > 0)
+        return launch_generated(c, c->grp[d].fn, enumgen_block_threads(c->model), c->grp_blocks_per_cu[d], n_sites, d_lk,
+                                d_flags, d_post, d_single, d_status, stream, enumgen_sites_per_chunk(c->model, d));
+      return launch_generated(c, c->lane.fn, enumgen_block_threads(c->model), c->lane_blocks_per_cu, n_sites, d_lk, d_flags,
+                              d_post, d_single, d_status, stream);
+    }
+  }
   return launch_bn_enum(c->plan, c->kp, grid_for(c, n_sites), c->d_img, c->d_tc, n_sites, d_lk, d_flags, d_post,
                         d_single, d_status, stream);
 }
@@ -335,6 +374,7 @@ extern "C" void famseq_destroy(famseq_ctx *c) {
     if (c->d_tc) (void)hipFree(c->d_tc);
     jit_unload(c->elim);
     jit_unload(c->lane);
+    for (JitKernel &k : c->grp) jit_unload(k);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_seq) (void)hipFree(c->d_seq);
     if (c->d_col) (void)hipFree(c->d_col);
@@ -364,6 +404,14 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
     return 0;
   }
   else if (k == "lane_min_sites") { c->lane_min_sites = value; return 0; }
+  else if (k == "group_digits") {
+    if (value < -1 || value > enumgen_max_group_digits(c->model))
+      return fail(c, FAMSEQ_E_ARG, "group_digits must be -1 (auto) or 0.." + std::to_string(enumgen_max_group_digits(c->model)) +
+                                       " (looped members of this pedigree's enumeration)");
+    if (value >= 0 && !load_lane(c, (int)value)) return fail(c, FAMSEQ_E_HIP, "lane kernel unavailable: " + c->lane_error);
+    c->group_digits = (int)value;
+    return 0;
+  }
   else if (k == "engine") {
     if (value != FAMSEQ_ENGINE_ENUM && value != FAMSEQ_ENGINE_ELIM) return fail(c, FAMSEQ_E_ARG, "engine must be 0 (enum) or 1 (elim)");
     if (value == FAMSEQ_ENGINE_ELIM) {
@@ -415,7 +463,12 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
              ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + ",\"elim_variant\":" + std::to_string(c->elim_variant) +
              ",\"elim_conditioned_members\":" + std::to_string(elim_conditioned_members(c->model)) +
              ",\"elim_blocks_per_cu\":" + std::to_string(c->elim_blocks_per_cu) + ",\"enum_lane_variant\":" +
-             std::to_string(c->lane_variant) + ",\"enum_lane_blocks_per_cu\":" + std::to_string(c->lane_blocks_per_cu) + "}";
+             std::to_string(c->lane_variant) + ",\"enum_lane_blocks_per_cu\":" + std::to_string(c->lane_blocks_per_cu) +
+             ",\"enum_group_digits\":" + std::to_string(c->group_digits) + ",\"enum_group_digits_max\":" +
+             std::to_string(enumgen_max_group_digits(c->model)) + ",\"enum_group_digits_last\":" +
+             std::to_string(c->last_group_digits) + ",\"enum_group_code_objects\":[";
+  for (int d = 1; d <= kEnumMaxGroupDigits; ++d) c->json += std::string(d > 1 ? "," : "") + "\"" + json_str(c->grp[d].path) + "\"";
+  c->json += "]}";
   return c->json.c_str();
 }
 

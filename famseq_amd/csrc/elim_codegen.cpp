@@ -378,6 +378,31 @@ int elim_block_threads(const famseq_model &m) {
   return m.n_members <= 10 ? 256 : 128;
 }
 
+// Statements of the single posterior (family.cpp:1426-1445) and of the shortcut vote (:767-789), the
+// same as in bn_kernel.hip; they read l<p>_<g> and tcf[], set single_fail / full, and (store) write
+// the normalised rows to row[].  Shared by every generated shell.
+std::string single_posterior_statements(const famseq_model &m, bool flags_pass, bool store, bool fence_single) {
+  std::ostringstream s;
+  const int N = m.n_members;
+  for (int p = 0; p < N; ++p) {
+    const int fk = m.gender[p] == 1 ? 0 : 1;
+    s << "    { const double a0 = l" << p << "_0, a1 = l" << p << "_1, a2 = l" << p << "_2;\n"
+      << "      const double p0 = a0 * tcf[" << fk * 27 << "], p1 = a1 * tcf[" << fk * 27 + 9 << "], p2 = a2 * tcf["
+      << fk * 27 + 18 << "];\n      const double s = (p0 + p1) + p2;";
+    if (flags_pass) s << " if (s <= 0) single_fail = true;";
+    s << "\n";
+    if (store)
+      s << "      row[" << 3 * p << "] = p0 / s; row[" << 3 * p + 1 << "] = p1 / s; row[" << 3 * p + 2 << "] = p2 / s;\n";
+    if (flags_pass && m.sequenced[p])
+      s << "      double big = 0; if (big < a0) big = a0; if (big < a1) big = a1; if (big < a2) big = a2;\n"
+        << "      const double sum = (a0 + a1) + a2; big = big / sum; if (big < lc) full = true;\n";
+    // fence: one member at a time (interleaved division sequences would spill)
+    s << "    }\n";
+    if (fence_single) s << "    asm volatile(\"\" ::: \"memory\");\n";
+  }
+  return s.str();
+}
+
 // The part every generated engine shares: I/O staging through padded LDS rows, the single
 // posterior, the shortcut vote and the status byte.  `body` runs for sites that need the full
 // computation; it reads l<p>_<g> and tcf[...], and must set bn_fail on a row sum <= 0.
@@ -503,26 +528,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "    const int fl = (tid < ns && flags_g) ? (flags_g[site0 + tid] & 3) : 0;\n"
     << "    const double *tcf = s_tc + fl * 108;\n"
     << "    bool single_fail = false, full = false, bn_fail = false;\n";
-  // statements of the single posterior (family.cpp:1426-1445) and of the shortcut vote (:767-789),
-  // the same as in bn_kernel.hip; `store` decides whether the normalised values are written
-  auto single_pass = [&](bool flags_pass, bool store) {
-    for (int p = 0; p < N; ++p) {
-      const int fk = m.gender[p] == 1 ? 0 : 1;
-      s << "    { const double a0 = l" << p << "_0, a1 = l" << p << "_1, a2 = l" << p << "_2;\n"
-        << "      const double p0 = a0 * tcf[" << fk * 27 << "], p1 = a1 * tcf[" << fk * 27 + 9 << "], p2 = a2 * tcf["
-        << fk * 27 + 18 << "];\n      const double s = (p0 + p1) + p2;";
-      if (flags_pass) s << " if (s <= 0) single_fail = true;";
-      s << "\n";
-      if (store)
-        s << "      row[" << 3 * p << "] = p0 / s; row[" << 3 * p + 1 << "] = p1 / s; row[" << 3 * p + 2 << "] = p2 / s;\n";
-      if (flags_pass && m.sequenced[p])
-        s << "      double big = 0; if (big < a0) big = a0; if (big < a1) big = a1; if (big < a2) big = a2;\n"
-          << "      const double sum = (a0 + a1) + a2; big = big / sum; if (big < lc) full = true;\n";
-      // fence: one member at a time (interleaved division sequences would spill)
-      s << "    }\n";
-      if (fence_single) s << "    asm volatile(\"\" ::: \"memory\");\n";
-    }
-  };
+  auto single_pass = [&](bool flags_pass, bool store) { s << single_posterior_statements(m, flags_pass, store, fence_single); };
   if (regs_l) {
     for (int p = 0; p < N; ++p)
       for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = row[" << 3 * p + gt << "];\n";
@@ -533,6 +539,8 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       << "    if (single_g) { STAGE_OUT(single_g); }\n"
       << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n"
       << "    if (full && !single_fail) {\n"
+      << "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;  // this lane's row in global memory\n"
+      << "      (void)lg;\n"
       << body
       << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << "    }\n";

@@ -21,6 +21,7 @@ std::string elim_source(const famseq_model &m, int variant);
 int elim_block_threads(const famseq_model &m);
 
 // Shared shell of the generated kernels (see elim_codegen.cpp).
+std::string single_posterior_statements(const famseq_model &m, bool flags_pass, bool store, bool fence_single);
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
                          bool chrx_loop = false, int row_doubles = 0);

@@ -112,7 +112,22 @@ Shape choose_shape(const famseq_model &m, int cap) {
 
 class Gen {
  public:
-  Gen(const famseq_model &m, const Shape &s, int row_len) : m_(m), s_(s), nu_((int)s.unrolled.size()), row_len_(row_len), outer_(s.outer) {}
+  // fixed: the `fixed` outermost looped members do not loop — their digits come from the lane's
+  // position in its group (fx0, fx1, ...: lanes-per-site mode, 3^fixed lanes share a site)
+  Gen(const famseq_model &m, const Shape &s, int row_len, int fixed = 0)
+      : m_(m), s_(s), nu_((int)s.unrolled.size()), row_len_(row_len), fixed_(fixed), outer_(s.outer) {}
+
+  // Lanes-per-site mode, second half (run by the group's first lane after a barrier): sum the G
+  // lanes' partial marginals in lane order (bit-reproducible), normalise, failure rule.
+  std::string reduce_body() const {
+    std::ostringstream o;
+    o << "#pragma unroll 1\n      for (int k = 0; k < W3; k += 3) {\n"
+      << "        double t0 = row[k], t1 = row[k + 1], t2 = row[k + 2];\n"
+      << "#pragma unroll 1\n        for (int j = 1; j < G; ++j) { t0 += row[j * ROW + k]; t1 += row[j * ROW + k + 1]; t2 += row[j * ROW + k + 2]; }\n"
+      << "        const double s = (t0 + t1) + t2; if (s <= 0) bn_fail = true;\n"
+      << "        row[k] = t0 / s; row[k + 1] = t1 / s; row[k + 2] = t2 / s;\n      }\n";
+    return o.str();
+  }
 
   // The per-step tables are plain expressions of the loop digits, so the compiler hoists each one
   // to the outermost loop whose digit it mentions.  Put the member whose digit feeds the most
@@ -190,7 +205,11 @@ class Gen {
         next += 3;
       }
     }
-    o_ << "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;\n";
+    for (int k = 0; k < fixed_; ++k) {  // this lane's digits of the members that do not loop
+      int div = 1;
+      for (int j = 0; j < k; ++j) div *= 3;
+      o_ << "      const int fx" << k << " = (sub / " << div << ") % 3;\n";
+    }
     joint_ = sl_ >= 2;
     if (const char *e = std::getenv("FAMSEQ_LANE_JOINT")) joint_ = joint_ && std::atoi(e) != 0;  // tuning aid
     for (int k = 0; k < nu_; ++k) {
@@ -227,6 +246,11 @@ class Gen {
           o_ << "      const double b" << s_.unrolled[nu_ - sl_ + j] << "_" << g << " = " << e << ";\n";
         }
     }
+    if (fixed_ > 0) {  // this lane's share of the marginals, unnormalised: reduce_body() sums the group's
+      for (int p = 0; p < s_.N; ++p)
+        for (int g = 0; g < 3; ++g) o_ << "      row[" << 3 * p + g << "] = b" << p << "_" << g << ";\n";
+      return o_.str();
+    }
     for (int p = 0; p < s_.N; ++p)
       o_ << "      { const double s = (b" << p << "_0 + b" << p << "_1) + b" << p << "_2; if (s <= 0) bn_fail = true;\n"
          << "        row[" << 3 * p << "] = b" << p << "_0 / s; row[" << 3 * p + 1 << "] = b" << p << "_1 / s; row["
@@ -239,6 +263,7 @@ class Gen {
   const Shape &s_;
   const int nu_;
   const int row_len_;  // doubles in the lane's LDS row (>= 3N, odd)
+  const int fixed_;    // outermost looped members whose digit is the lane's (lanes-per-site mode)
   std::vector<int> outer_;  // looped members, outermost first
   std::ostringstream o_;
   int uid_ = 0;
@@ -274,9 +299,12 @@ class Gen {
     const std::string g = "g" + num(p), ind(6 + 2 * k, ' ');
     const std::string lk_g = l_in_lds_ ? "row[" + num(3 * no + 3 * (int)k) + " + " + g + "]"
                                        : "(" + g + " == 0 ? l" + num(p) + "_0 : (" + g + " == 1 ? l" + num(p) + "_1 : l" + num(p) + "_2))";
-    o_ << "#pragma unroll 1\n"  // keep the walk rolled: an unrolled outer loop triples the block's live state
-       << ind << "for (int " << g << " = 0; " << g << " < 3; ++" << g << ") {\n"
-       << ind << "  const double f" << p << " = tcf[" << t_index(p, g, -1, -1) << "] * " << lk_g << ";\n"
+    if ((int)k < fixed_)
+      o_ << ind << "{ const int " << g << " = fx" << k << ";  // one digit per lane of the group\n";
+    else
+      o_ << "#pragma unroll 1\n"  // keep the walk rolled: an unrolled outer loop triples the block's live state
+         << ind << "for (int " << g << " = 0; " << g << " < 3; ++" << g << ") {\n";
+    o_ << ind << "  const double f" << p << " = tcf[" << t_index(p, g, -1, -1) << "] * " << lk_g << ";\n"
        << ind << "  const double P" << p << " = " << P << " * f" << p << ";\n"
        << ind << "  double acc" << p << " = 0;\n"
        << bucket_[k + 1];
@@ -580,11 +608,93 @@ int enumgen_block_threads(const famseq_model &m) {
   return m.n_members <= 10 ? 256 : 128;
 }
 
-std::string enumgen_source(const famseq_model &m, int variant) {
+int enumgen_max_group_digits(const famseq_model &m) {
+  int cap = 6;
+  if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);
+  return std::min<int>(kEnumMaxGroupDigits, (int)choose_shape(m, cap).outer.size());
+}
+
+int enumgen_sites_per_chunk(const famseq_model &m, int group_digits) {
+  int g = 1;
+  for (int k = 0; k < group_digits; ++k) g *= 3;
+  return enumgen_block_threads(m) / g;
+}
+
+namespace {
+
+// Shell of the lanes-per-site mode (small batches): G = 3^d consecutive lanes share a site, each
+// walks the digits (fx0, fx1, ...) of the d outermost looped members given by its position in the
+// group, i.e. 1/G of the enumeration; the partial marginals meet in the lanes' LDS rows and the
+// group's first lane adds them in lane order, normalises and applies the failure rule.  A site's
+// latency drops by G and G times as many lanes are busy, which is what a batch too small to give
+// every lane of the chip a site of its own needs (one lane per site: 0.17 ms for anything up to 131 k
+// 10-member sites).  I/O is a plain strided walk — this shell never sees a large batch.
+std::string grouped_shell(const famseq_model &m, const std::string &comment, const std::string &body, const std::string &reduce,
+                          int bt, int min_waves, bool fence_single, int row_doubles, int group) {
+  const int N = m.n_members, W3 = 3 * N, ROW = (row_doubles > 0 ? row_doubles : W3) | 1;
+  std::ostringstream s;
+  s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
+    << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
+    << "#define W3 " << W3 << "\n#define ROW " << ROW << "\n#define BT " << bt << "\n#define G " << group << "\n#define SPC (BT / G)\n"
+    << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
+    // rows of the groups' first lanes -> global, coalesced
+    << "#define STAGE_OUT(Gp) { double *g_ = (Gp) + site0 * W3; \\\n"
+    << "  for (int e = tid; e < ns * W3; e += BT) { const int s_ = e / W3; g_[e] = s_io[s_ * G * ROW + (e - s_ * W3)]; } }\n"
+    << "extern \"C\" __global__ __launch_bounds__(BT, " << min_waves << ") void famseq_enum_lane(const double *__restrict__ lk_g,\n"
+    << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
+    << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
+    << "  __shared__ double s_io[BT * ROW];  // one padded row per lane\n"
+    << "  __shared__ double s_tc[432];\n"
+    << "  const int tid = threadIdx.x;\n"
+    << "  for (int i = tid; i < 432; i += BT) s_tc[i] = tc_g[i];\n"
+    << "  const int sidx = tid / G, sub = tid - sidx * G;  // site within the chunk, lane within the group\n"
+    << "  const long chunks = (n_sites + SPC - 1) / SPC;\n"
+    << "  const long per_wg = (chunks + gridDim.x - 1) / gridDim.x;\n"
+    << "  const long c_lo = (long)blockIdx.x * per_wg, c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;\n"
+    << "  const double kNaN = __builtin_nan(\"\");\n"
+    << "  double *row = s_io + tid * ROW;\n"
+    << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
+    << "    const long site0 = ch * SPC;\n"
+    << "    const int ns = n_sites - site0 < SPC ? (int)(n_sites - site0) : SPC;\n"
+    << "    const bool act = sidx < ns;  // lanes beyond the chunk's sites compute on its first site and store nothing\n"
+    << "    const long site = site0 + (act ? sidx : 0);\n"
+    << "    const double *lg = lk_g + site * W3;\n"
+    << "    LDS_BARRIER();  // the previous chunk's rows have been stored; the table is in LDS\n"
+    << "    const int fl = flags_g ? (flags_g[site] & 3) : 0;\n"
+    << "    const double *tcf = s_tc + fl * 108;\n"
+    << "    bool single_fail = false, full = false, bn_fail = false;\n";
+  for (int p = 0; p < N; ++p)
+    for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = lg[" << 3 * p + gt << "];\n";
+  s << single_posterior_statements(m, true, true, fence_single)
+    << "    if (!act) full = false;\n"
+    << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
+    << "    LDS_BARRIER();\n"
+    << "    if (single_g) { STAGE_OUT(single_g); }\n"
+    << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n"
+    << "    if (full && !single_fail) {\n"
+    << body
+    << "    }\n"
+    << "    LDS_BARRIER();  // every lane's share of the marginals is in its row\n"
+    << "    if (full && !single_fail && sub == 0) {\n"
+    << reduce
+    << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
+    << "    }\n"
+    << "    LDS_BARRIER();\n"
+    << "    STAGE_OUT(post_g);\n"
+    << "    if (status_g && act && sub == 0) status_g[site] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
+    << "  }\n}\n";
+  return s.str();
+}
+
+}  // namespace
+
+std::string enumgen_source(const famseq_model &m, int variant, int group_digits) {
   int cap = 6;
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);  // tuning aid
   const Shape s = choose_shape(m, cap);
   if (s.unrolled.empty()) throw std::runtime_error("enumeration codegen: empty unrolled set");
+  if (group_digits < 0 || group_digits > std::min<int>(kEnumMaxGroupDigits, (int)s.outer.size()))
+    throw std::runtime_error("enumeration codegen: more group digits than looped members");
   const int bt = enumgen_block_threads(m);
   // The lane's LDS row: 3N doubles padded to an odd count, plus — while two workgroups per CU still
   // fit in the 160 KB — room for the likelihoods of unrolled members whose tables are rebuilt inside
@@ -599,13 +709,24 @@ std::string enumgen_source(const famseq_model &m, int variant) {
     const int fit = ((160 * 1024 / 2 - 432 * 8) / (bt * 8) - 1) | 1;  // odd, two workgroups per CU
     if (want > row_len) row_len = std::min(want, std::max(row_len, fit));
   }
+  int group = 1;
+  for (int k = 0; k < group_digits; ++k) group *= 3;
   std::string what = "3^N enumeration, lane per site, " + std::to_string(s.outer.size()) + " looped + " +
                      std::to_string(s.unrolled.size()) + " unrolled members, variant " + std::to_string(variant);
+  if (group > 1)
+    what = "3^N enumeration, " + std::to_string(group) + " lanes per site (" + std::to_string(group_digits) + " of " +
+           std::to_string(s.outer.size()) + " looped members' digits on lanes), " + std::to_string(s.unrolled.size()) +
+           " unrolled members, variant " + std::to_string(variant);
   int min_waves = bt / 128;
   if (const char *e = std::getenv("FAMSEQ_LANE_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
+  Gen gen(m, s, row_len, group_digits);
+  if (group > 1) {
+    const std::string body = gen.body();
+    return grouped_shell(m, what, body, gen.reduce_body(), bt, min_waves, variant >= 1, row_len, group);
+  }
   // regs_l: LDS-resident likelihoods measured 17% slower.  variant 0: the members of the single
   // posterior overlap, 1: fenced one from the other (fewer registers)
-  return kernel_shell(m, "famseq_enum_lane", what, Gen(m, s, row_len).body(), bt, min_waves, /*regs_l=*/true, variant >= 1,
+  return kernel_shell(m, "famseq_enum_lane", what, gen.body(), bt, min_waves, /*regs_l=*/true, variant >= 1,
                       /*chrx_loop=*/false, row_len);
 }
 

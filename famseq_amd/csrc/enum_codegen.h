@@ -10,7 +10,12 @@ namespace famseq {
 
 // HIP source of `extern "C" __global__ famseq_enum_lane(lk, flags, post, single, status, n_sites, tc, lc)`.
 constexpr int kEnumVariants = 2;  // see elim_codegen.h
-std::string enumgen_source(const famseq_model &m, int variant);
+// group_digits = d > 0: lanes-per-site mode for small batches — 3^d consecutive lanes share a site, each
+// taking one combination of the d outermost looped members' digits (d <= enumgen_max_group_digits)
+constexpr int kEnumMaxGroupDigits = 4;
+std::string enumgen_source(const famseq_model &m, int variant, int group_digits = 0);
+int enumgen_max_group_digits(const famseq_model &m);
+int enumgen_sites_per_chunk(const famseq_model &m, int group_digits);  // sites a workgroup handles per chunk
 int enumgen_block_threads(const famseq_model &m);
 // One-line description of the lane kernel's tiling (which members are looped / unrolled).
 std::string enumgen_describe(const famseq_model &m);

@@ -31,7 +31,46 @@ static idx3_ threadIdx{0}, blockIdx{0}, gridDim{1};
 """
 
 
-def host_source(src: str) -> str:
+# Lanes-per-site kernels need their G lanes to meet at the workgroup barriers: the lanes are host
+# threads here (thread-local threadIdx, the `static` LDS arrays shared), the barrier a pthread barrier.
+SHIM_THREADS = r"""
+#include <cmath>
+#include <pthread.h>
+#include <thread>
+#include <vector>
+struct v2d { double x, y; };
+struct idx3_ { int x; };
+static thread_local idx3_ threadIdx{0};
+static idx3_ blockIdx{0}, gridDim{1};
+static pthread_barrier_t wg_barrier_;
+#define __global__
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#define famseq_enum_lane famseq_enum_lane_one_thread
+"""
+DRIVER_THREADS = r"""
+#undef famseq_enum_lane
+extern "C" void famseq_enum_lane(const double *lk, const unsigned char *fl, double *post, double *single,
+                                 unsigned char *st, long n, const double *tc, double lc) {
+  pthread_barrier_init(&wg_barrier_, nullptr, BT);
+  std::vector<std::thread> lanes;
+  for (int t = 0; t < BT; ++t)
+    lanes.emplace_back([=] { threadIdx.x = t; famseq_enum_lane_one_thread(lk, fl, post, single, st, n, tc, lc); });
+  for (auto &l : lanes) l.join();
+  pthread_barrier_destroy(&wg_barrier_);
+}
+"""
+
+
+def host_source(src: str, threads=False) -> str:
+    if threads:
+        src = src.replace("#include <hip/hip_runtime.h>", SHIM_THREADS)
+        src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() pthread_barrier_wait(&wg_barrier_)", src)
+        src = src.replace('extern "C" __global__', "static") + DRIVER_THREADS
+        src = re.sub(r'asm volatile\(""[^\n;]*\);', "", src)
+        assert "asm" not in src
+        return src
     src = src.replace("#include <hip/hip_runtime.h>", SHIM)
     src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() (void)0", src)
     src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "")
@@ -111,6 +150,23 @@ def build_host_kernel(model, kind, tmp_path, monkeypatch):
                      FAMSEQ_LANE_MINWAVES="1").items():
         monkeypatch.setenv(k, v)
     ctx = fs.Context(model, device=-1)
+    if kind.startswith("group"):  # lanes-per-site mode: "group<d>" = 3^d lanes per site, two sites per workgroup
+        d = int(kind[5:])
+        monkeypatch.setenv("FAMSEQ_LANE_BT", str(2 * 3 ** d + 1))  # + one lane that belongs to no group
+        ctx.close()
+        ctx = fs.Context(model, device=-1)
+        ctx.set_option("group_digits", d)
+        obj, entry = ctx.plan()["enum_group_code_objects"][d - 1], "famseq_enum_lane"
+        ctx.close()
+        src = open(obj[:-6] + ".hip").read()
+        assert "#define G %d\n" % 3 ** d in src
+        cpp, so = str(cache / "k.cpp"), str(cache / "k.so")
+        open(cpp, "w").write(host_source(src, threads=True))
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-w", "-shared", "-fPIC", "-pthread", "-o", so, cpp])
+        fn = getattr(C.CDLL(so), entry)
+        fn.restype = None
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_double]
+        return fn
     if kind == "lane":
         ctx.set_option("enum_impl", 1)
         obj, entry = ctx.plan()["enum_lane_code_object"], "famseq_enum_lane"
@@ -178,3 +234,30 @@ def test_conditioning_on_a_first_cousin_marriage(tmp_path, monkeypatch):
     ok = (st & 3) == 0
     assert ok.sum() > 20
     np.testing.assert_allclose(post[ok], ref[0][ok], rtol=1e-10, atol=0)
+
+
+GROUP_CASES = [c for c in CASES if c.name in ("bn_synth:ped10", "bn_synth:ped10_x", "bn_synth:chain7", "bn_vcf:fam01", "bn_synth:quad_mu0")]
+
+
+@pytest.mark.parametrize("d", [1, 2, 4])
+@pytest.mark.parametrize("case", GROUP_CASES, ids=[c.name for c in GROUP_CASES])
+def test_lanes_per_site_mode_matches_the_fixtures(case, d, tmp_path, monkeypatch):
+    """The small-batch form of the enumeration kernel (3^d lanes share a site, each walking one
+    combination of the d outermost looped members' digits; partial marginals summed through LDS by
+    the group's first lane): the generated source with its lanes as host threads and the workgroup
+    barrier as a pthread barrier, against the fixtures — ragged last chunk and an idle lane included."""
+    ped = case.pedigree()
+    model = fs.make_model(ped, **case.consts)
+    probe = fs.Context(model, device=-1)
+    dmax = probe.plan()["enum_group_digits_max"]
+    probe.close()
+    if d > dmax:
+        pytest.skip("this pedigree's enumeration has %d looped member(s)" % dmax)
+    fn = build_host_kernel(model, "group%d" % d, tmp_path, monkeypatch)
+    n = min(len(case.lk), 7)  # 2 sites per chunk: three whole chunks and a ragged one
+    post, single, st = run_host(fn, model, case.lk[:n], case.flags[:n])
+    assert np.array_equal(st, case.status[:n])
+    ok, s_ok = (case.status[:n] & 3) == 0, (case.status[:n] & 3) != 1
+    assert np.array_equal(single[s_ok], case.single[:n][s_ok])
+    np.testing.assert_allclose(post[ok], case.post[:n][ok], rtol=1e-12, atol=0)
+    assert np.all(np.isnan(post[~ok]))
