@@ -240,19 +240,22 @@ bool load_lane(famseq_ctx *c, int d = 0) {
   }
 }
 
-// How many of the outermost looped members' digits go on lanes for a batch of n_sites: the d that
-// minimises rounds(d) / 3^d, where a round is one lane-kernel chunk time and the chip holds
-// n_cus * 512 lanes (two waves per SIMD) per round; ties go to the smaller group.
+// How many of the outermost looped members' digits go on lanes for a batch of n_sites.  Cost model
+// (measured on the 10-member benchmark pedigree, tools/small_batch_rates.py): a lane's work is its
+// share of the enumeration, 3^N / 3^d configurations, plus what every lane of a group repeats (single
+// posterior, tables of the fixed levels, its columns of the reduction: about 250 N configuration
+// times); lanes run at full speed while there is at most one wave per SIMD (n_cus * 256 lanes), beyond
+// that the time grows with the lane count.  More lanes per site pay while the batch leaves SIMDs idle.
 int pick_group_digits(const famseq_ctx *c, int64_t n_sites) {
   const int dmax = enumgen_max_group_digits(c->model);
   if (c->group_digits >= 0) return std::min(c->group_digits, dmax);
-  const double lanes = double(std::max(1, c->n_cus)) * 512.0;
+  const double full_speed_lanes = double(std::max(1, c->n_cus)) * 256.0;
+  const double configs = std::pow(3.0, c->model.n_members), per_lane = 250.0 * c->model.n_members;
   int best = 0;
   double best_t = 0;
   for (int d = 0, g = 1; d <= dmax; ++d, g *= 3) {
-    const double rounds = std::ceil(double(n_sites) * g / lanes);
-    const double t = rounds / g + (d ? 0.002 * g : 0.0);  // + the group's reduction, a little per lane
-    if (d == 0 || t < best_t * 0.95) {
+    const double t = std::max(1.0, double(n_sites) * g / full_speed_lanes) * (configs / g + (d ? per_lane : 0.0));
+    if (d == 0 || t < best_t * 0.9) {
       best = d;
       best_t = t;
     }

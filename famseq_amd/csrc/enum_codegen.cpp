@@ -117,13 +117,12 @@ class Gen {
   Gen(const famseq_model &m, const Shape &s, int row_len, int fixed = 0)
       : m_(m), s_(s), nu_((int)s.unrolled.size()), row_len_(row_len), fixed_(fixed), outer_(s.outer) {}
 
-  // Lanes-per-site mode, second half (run by the group's first lane after a barrier): sum the G
-  // lanes' partial marginals in lane order (bit-reproducible), normalise, failure rule.
+  // Lanes-per-site mode, last step (the group's first lane, after the column sums): normalise,
+  // failure rule (family.cpp:943-954).
   std::string reduce_body() const {
     std::ostringstream o;
     o << "#pragma unroll 1\n      for (int k = 0; k < W3; k += 3) {\n"
-      << "        double t0 = row[k], t1 = row[k + 1], t2 = row[k + 2];\n"
-      << "#pragma unroll 1\n        for (int j = 1; j < G; ++j) { t0 += row[j * ROW + k]; t1 += row[j * ROW + k + 1]; t2 += row[j * ROW + k + 2]; }\n"
+      << "        const double t0 = row[k], t1 = row[k + 1], t2 = row[k + 2];\n"
       << "        const double s = (t0 + t1) + t2; if (s <= 0) bn_fail = true;\n"
       << "        row[k] = t0 / s; row[k + 1] = t1 / s; row[k + 2] = t2 / s;\n      }\n";
     return o.str();
@@ -624,8 +623,8 @@ namespace {
 
 // Shell of the lanes-per-site mode (small batches): G = 3^d consecutive lanes share a site, each
 // walks the digits (fx0, fx1, ...) of the d outermost looped members given by its position in the
-// group, i.e. 1/G of the enumeration; the partial marginals meet in the lanes' LDS rows and the
-// group's first lane adds them in lane order, normalises and applies the failure rule.  A site's
+// group, i.e. 1/G of the enumeration; the partial marginals meet in the lanes' LDS rows, the group
+// adds them column by column in lane order, its first lane normalises and applies the failure rule.  A site's
 // latency drops by G and G times as many lanes are busy, which is what a batch too small to give
 // every lane of the chip a site of its own needs (one lane per site: 0.17 ms for anything up to 131 k
 // 10-member sites).  I/O is a plain strided walk — this shell never sees a large batch.
@@ -675,6 +674,17 @@ std::string grouped_shell(const famseq_model &m, const std::string &comment, con
     << body
     << "    }\n"
     << "    LDS_BARRIER();  // every lane's share of the marginals is in its row\n"
+    // column sums over the group's rows, the columns dealt round the group's lanes (3N / G + 1 of them
+    // each), every column in lane order 0..G-1 (bit-reproducible); the sums land in the first lane's row
+    << "    if (full && !single_fail) {\n"
+    << "      double *lead = row - sub * ROW;\n"
+    << "#pragma unroll 1\n"
+    << "      for (int k = sub; k < W3; k += G) {\n"
+    << "        double t = lead[k];\n"
+    << "#pragma unroll 1\n"
+    << "        for (int j = 1; j < G; ++j) t += lead[j * ROW + k];\n"
+    << "        lead[k] = t;\n      }\n    }\n"
+    << "    LDS_BARRIER();\n"
     << "    if (full && !single_fail && sub == 0) {\n"
     << reduce
     << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"

@@ -57,7 +57,7 @@ def test_batch_sizes_around_the_chunk_boundaries(d):
         check(ctx.bn_batch(lk[:n], flags[:n]), tuple(x[:n] for x in ref), "d=%d n=%d" % (d, n))
     # optional outputs absent
     post, single, st = ctx.bn_batch(lk[:spc + 1], flags[:spc + 1], want_single=False, want_status=False)
-    np.testing.assert_allclose(post[:5], ref[0][:5], rtol=RTOL)
+    np.testing.assert_allclose(post, ref[0][:spc + 1], rtol=RTOL)
     ctx.close()
 
 
@@ -77,7 +77,7 @@ def test_group_size_follows_the_batch_size():
             ref = post
         np.testing.assert_allclose(post, ref[:n], rtol=1e-12, atol=0)
         assert np.all(st == 0)
-    assert seen[140_000] == 0 and seen[30] == 4, seen
+    assert seen[140_000] == 0 and seen[30] == 4 and seen[12_000] >= 1, seen
     assert all(seen[a] <= seen[b] for a, b in zip(list(seen)[:-1], list(seen)[1:])), seen
     with pytest.raises(fs.FamseqError, match="group_digits"):
         ctx.set_option("group_digits", 5)
