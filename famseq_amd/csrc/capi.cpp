@@ -55,7 +55,7 @@ struct famseq_ctx {
   JitKernel grp[kEnumMaxGroupDigits + 1]{};
   int grp_blocks_per_cu[kEnumMaxGroupDigits + 1] = {};
   int group_digits = -1, last_group_digits = 0;
-  int64_t lane_min_sites = 1024;  // below this the compiled-in team kernel answers at once (no per-pedigree compile for tiny calls)
+  int64_t lane_min_sites = 256;  // below this the compiled-in team kernel answers at once (no per-pedigree compile for tiny calls)
   // device constants
   uint32_t *d_img = nullptr;
   double *d_tc = nullptr;

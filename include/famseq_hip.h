@@ -109,10 +109,16 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *   "grid_blocks"   persistent grid size (0 = auto: CUs x resident blocks)
  *   "chunk_sites"   host-staging chunk of famseq_bn_batch (0 = auto)
  *   "enum_impl"     which enumeration kernel serves FAMSEQ_ENGINE_ENUM: 0 = the team-per-site kernel
- *                   compiled into the library (any batch size, any pedigree); 1 = the lane-per-site
- *                   kernel generated and compiled for this pedigree (fastest on large batches);
- *                   -1 (default) = lane kernel for batches of >= "lane_min_sites" (14336) sites when it
- *                   can be built, team kernel otherwise
+ *                   compiled into the library (any batch size, any pedigree, no compiler needed); 1 = the
+ *                   kernel generated and compiled for this pedigree; -1 (default) = the generated kernel
+ *                   for batches of >= "lane_min_sites" (256) sites when it can be built, the team kernel
+ *                   otherwise (tiny calls never wait for a compile)
+ *   "group_digits"  the generated kernel's lanes per site, 3^d: d = 0 one lane per site (large batches),
+ *                   d = 1..4 lanes-per-site mode for batches too small to give every lane of the chip a
+ *                   site (each lane of a group enumerates one combination of the d outermost looped
+ *                   members' genotypes; the group sums through LDS); -1 (default) = chosen per call from
+ *                   the batch size.  At most the number of looped members of the pedigree's enumeration
+ *                   (famseq_plan_json "enum_group_digits_max"; 0 for pedigrees of up to 6 members)
  *   "engine"        FAMSEQ_ENGINE_ENUM (default) or FAMSEQ_ENGINE_ELIM; selecting ELIM generates the
  *                   kernel for this pedigree, compiles it with hipcc (cached on disk) and fails with
  *                   FAMSEQ_E_ARG on a pedigree whose loops need more than three conditioned members

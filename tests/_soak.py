@@ -39,6 +39,8 @@ def run_seed(seed, max_n=10, threads=8):
     plan = probe.plan()
     probe.close()
     engines = [("team", dict(enum_impl=0)), ("lane", dict(enum_impl=1))]
+    if plan["enum_group_digits_max"] >= 1:  # lanes-per-site mode, 3 or 9 lanes per site
+        engines.append(("group", dict(enum_impl=1, group_digits=min(2, plan["enum_group_digits_max"]))))
     if plan["elim_supported"]:
         engines.append(("elim", dict(engine=fs.ENGINE_ELIM)))
     res, bad = [], []
@@ -69,6 +71,8 @@ def run_seed(seed, max_n=10, threads=8):
         v[np.all(pl[:, j] == fs.PL_MISSING, axis=1)] = 1.0
         lk2[:, mbr] = v
     for name, opt in engines[1:]:
+        if name == "group":
+            continue
         ctx = fs.Context(model, **opt)
         a = ctx.bn_call_batch(seq, lk=lk2, flags=flags)
         b = ctx.bn_call_batch(seq, pl16=pl, flags=flags)
