@@ -27,6 +27,18 @@
 
 using namespace famseq;
 
+// The fused call path's side of a generated kernel's argument list (kCallArgs): packed PLs in, GPP / FPP /
+// FGT out.  All null on the plain path.
+struct CallIO {  // = struct fs_call_args of the generated source (elim_codegen.cpp kCallHelpers)
+  const uint16_t *pl = nullptr;
+  const double *lut = nullptr;
+  const int32_t *col = nullptr, *seq = nullptr;
+  double *gpp = nullptr, *fpp = nullptr;
+  int8_t *fgt = nullptr;
+  int32_t n_seq = 0;
+  uint32_t magic_w = 0, magic_n = 0;
+};
+
 struct famseq_ctx {
   famseq_model model{};
   PlanOptions opt{};
@@ -40,6 +52,8 @@ struct famseq_ctx {
   int64_t chunk_sites = 0;
   int engine = FAMSEQ_ENGINE_ENUM;
   JitKernel elim{};      // generated sum-product kernel (engine = FAMSEQ_ENGINE_ELIM)
+  JitKernel elim_call{}, lane_call{};  // their fused call-path forms (famseq_bn_call_batch), built on first use
+  int elim_call_blocks_per_cu = 0, lane_call_blocks_per_cu = 0;
   int elim_blocks_per_cu = 0;
   int elim_variant = -1, lane_variant = -1;  // which generator variant jit_pick_variant took
   // enumeration engine: the team-per-site kernel is compiled into the library; the lane-per-site
@@ -55,6 +69,7 @@ struct famseq_ctx {
   JitKernel grp[kEnumMaxGroupDigits + 1]{};
   int grp_blocks_per_cu[kEnumMaxGroupDigits + 1] = {};
   int group_digits = -1, last_group_digits = 0;
+  int lane_reads_rows = -1;  // does the lane kernel re-read fp64 rows from global memory (unknown until asked)
   int64_t lane_min_sites = 256;  // below this the compiled-in team kernel answers at once (no per-pedigree compile for tiny calls)
   // device constants
   uint32_t *d_img = nullptr;
@@ -75,6 +90,7 @@ struct famseq_ctx {
   int8_t *d_fgt[kSlots] = {};
   double *d_lut = nullptr;
   int32_t *d_seq = nullptr, *d_col = nullptr;
+  CallIO *d_call[kSlots] = {};  // the generated kernels' call-path arguments, one per slot
   std::vector<int32_t> seq_members;
   std::string err, json;
 };
@@ -249,6 +265,7 @@ bool load_lane(famseq_ctx *c, int d = 0) {
 int pick_group_digits(const famseq_ctx *c, int64_t n_sites) {
   const int dmax = enumgen_max_group_digits(c->model);
   if (c->group_digits >= 0) return std::min(c->group_digits, dmax);
+  if (c->enum_impl == 1) return 0;  // an explicit choice of the lane-per-site kernel is exactly that kernel
   const double full_speed_lanes = double(std::max(1, c->n_cus)) * 256.0;
   const double configs = std::pow(3.0, c->model.n_members), per_lane = 250.0 * c->model.n_members;
   int best = 0;
@@ -265,7 +282,7 @@ int pick_group_digits(const famseq_ctx *c, int64_t n_sites) {
 
 hipError_t launch_generated(famseq_ctx *c, hipFunction_t fn, int bt, int blocks_per_cu, int64_t n_sites,
                             const double *d_lk, const uint8_t *d_flags, double *d_post, double *d_single,
-                            uint8_t *d_status, hipStream_t stream, int sites_per_chunk = 0) {
+                            uint8_t *d_status, hipStream_t stream, int sites_per_chunk = 0, const CallIO *d_call = nullptr) {
   const int spc = sites_per_chunk > 0 ? sites_per_chunk : bt;
   const int64_t chunks = (n_sites + spc - 1) / spc;
   int64_t resident = c->grid_override > 0 ? c->grid_override : int64_t(c->n_cus) * blocks_per_cu;
@@ -273,7 +290,7 @@ hipError_t launch_generated(famseq_ctx *c, hipFunction_t fn, int bt, int blocks_
   long ns = (long)n_sites;
   double lc = c->model.lc;
   const double *tc = c->d_tc;
-  void *args[] = {&d_lk, &d_flags, &d_post, &d_single, &d_status, &ns, &tc, &lc};
+  void *args[] = {&d_lk, &d_flags, &d_post, &d_single, &d_status, &ns, &tc, &lc, &d_call};  // the plain forms take the first eight
   return hipModuleLaunchKernel(fn, grid, 1, 1, (unsigned)bt, 1, 1, 0, stream, args, nullptr);
 }
 
@@ -300,6 +317,65 @@ hipError_t launch_engine(famseq_ctx *c, int64_t n_sites, const double *d_lk, con
   }
   return launch_bn_enum(c->plan, c->kp, grid_for(c, n_sites), c->d_img, c->d_tc, n_sites, d_lk, d_flags, d_post,
                         d_single, d_status, stream);
+}
+
+// The fused call path: one launch does PL -> likelihood, posterior, Phred scaling and the genotype call
+// (famseq_bn_call_batch).  Served by the generated kernels in their one-lane-per-site form; returns
+// false when this batch goes through the separate stages instead (team kernel, lanes-per-site mode, or
+// a lane kernel that re-reads fp64 rows from global memory while the input is packed).
+// Load (once) the call-path form of a generated kernel.  False when it cannot be built.
+bool load_call_kernel(famseq_ctx *c, bool elim) {
+  JitKernel &k = elim ? c->elim_call : c->lane_call;
+  if (k.fn) return true;
+  if (c->lane_failed) return false;
+  try {
+    const famseq_model &mdl = c->model;
+    const std::string src = elim ? jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants)
+                                 : jit_pick_variant([&mdl](int v) { return enumgen_source(mdl, v, 0, true); }, kEnumVariants);
+    if (c->device < 0) {
+      k.path = jit_compile(src);
+      return true;
+    }
+    if (hipSetDevice(c->device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+    k = jit_load(src, elim ? "famseq_elim" : "famseq_enum_lane");
+    int nb = 0;
+    const int bt = elim ? elim_block_threads(c->model) : enumgen_block_threads(c->model);
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, bt, 0) != hipSuccess) nb = 1;
+    (elim ? c->elim_call_blocks_per_cu : c->lane_call_blocks_per_cu) = nb > 0 ? nb : 1;
+    return true;
+  } catch (const std::exception &e) {
+    c->lane_failed = true;
+    c->lane_error = e.what();
+    return false;
+  }
+}
+
+// The fused call path: one launch does PL -> likelihood, posterior, Phred scaling and the genotype call
+// (famseq_bn_call_batch).  Served by the call-path forms of the generated kernels (one lane per site);
+// returns false when this batch goes through the separate stages instead (team kernel, lanes-per-site
+// mode, or a lane kernel that re-reads fp64 rows from global memory while the input is packed).
+bool launch_engine_fused(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, uint8_t *d_status,
+                         CallIO io, CallIO *d_io, hipStream_t stream, hipError_t *err) {
+  const bool elim = c->engine == FAMSEQ_ENGINE_ELIM;
+  if (!elim) {
+    const bool want_lane = c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites);
+    if (!want_lane || pick_group_digits(c, n_sites) != 0) return false;
+    if (io.pl) {
+      if (c->lane_reads_rows < 0) c->lane_reads_rows = enumgen_reads_global_rows(c->model) ? 1 : 0;
+      if (c->lane_reads_rows) return false;
+    }
+  }
+  if (!load_call_kernel(c, elim)) return false;
+  // e / d for e < 2^16, d <= 60 as the high word of e * (2^32 / d + 1): exact (io_kernels.hip)
+  io.magic_w = 0xFFFFFFFFu / uint32_t(3 * io.n_seq) + 1;
+  io.magic_n = 0xFFFFFFFFu / uint32_t(io.n_seq) + 1;
+  *err = hipMemcpyAsync(d_io, &io, sizeof io, hipMemcpyHostToDevice, stream);  // pageable source: staged before it returns
+  if (*err != hipSuccess) return true;
+  if (!elim) c->last_group_digits = 0;
+  *err = launch_generated(c, elim ? c->elim_call.fn : c->lane_call.fn, elim ? elim_block_threads(c->model) : enumgen_block_threads(c->model),
+                          elim ? c->elim_call_blocks_per_cu : c->lane_call_blocks_per_cu, n_sites, d_lk, d_flags, nullptr, nullptr,
+                          d_status, stream, 0, d_io);
+  return true;
 }
 
 }  // namespace
@@ -377,10 +453,14 @@ extern "C" void famseq_destroy(famseq_ctx *c) {
     if (c->d_tc) (void)hipFree(c->d_tc);
     jit_unload(c->elim);
     jit_unload(c->lane);
+    jit_unload(c->elim_call);
+    jit_unload(c->lane_call);
     for (JitKernel &k : c->grp) jit_unload(k);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_seq) (void)hipFree(c->d_seq);
     if (c->d_col) (void)hipFree(c->d_col);
+    for (int s = 0; s < famseq_ctx::kSlots; ++s)
+      if (c->d_call[s]) (void)hipFree(c->d_call[s]);
     for (int s = 0; s < famseq_ctx::kStages; ++s)
       if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
     for (int s = 0; s < famseq_ctx::kSlots; ++s)
@@ -407,6 +487,13 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
     return 0;
   }
   else if (k == "lane_min_sites") { c->lane_min_sites = value; return 0; }
+  else if (k == "call_kernels") {  // build (and on a device ctx load) the fused call-path forms now rather than on first use
+    if (value != 1) return fail(c, FAMSEQ_E_ARG, "call_kernels takes 1");
+    if (!load_call_kernel(c, false)) return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable: " + c->lane_error);
+    if (elim_supported(c->model, nullptr) && !load_call_kernel(c, true))
+      return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable: " + c->lane_error);
+    return 0;
+  }
   else if (k == "group_digits") {
     if (value < -1 || value > enumgen_max_group_digits(c->model))
       return fail(c, FAMSEQ_E_ARG, "group_digits must be -1 (auto) or 0.." + std::to_string(enumgen_max_group_digits(c->model)) +
@@ -471,7 +558,8 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
              std::to_string(enumgen_max_group_digits(c->model)) + ",\"enum_group_digits_last\":" +
              std::to_string(c->last_group_digits) + ",\"enum_group_code_objects\":[";
   for (int d = 1; d <= kEnumMaxGroupDigits; ++d) c->json += std::string(d > 1 ? "," : "") + "\"" + json_str(c->grp[d].path) + "\"";
-  c->json += "]}";
+  c->json += "],\"enum_lane_call_code_object\":\"" + json_str(c->lane_call.path) + "\",\"elim_call_code_object\":\"" +
+             json_str(c->elim_call.path) + "\"}";
   return c->json.c_str();
 }
 
@@ -552,6 +640,7 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_gpp[s]), cap * seqcap * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_fpp[s]), cap * seqcap * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_fgt[s]), cap * seqcap));
+        if (!c->d_call[s]) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_call[s]), sizeof(CallIO)));
       }
     }
     c->slot_sites = cap;
@@ -594,14 +683,32 @@ int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int6
     HIP_TRY(c, hipEventRecord(c->ev_in[s], s_in));
     // compute
     HIP_TRY(c, hipStreamWaitEvent(s_k, c->ev_in[s], 0));
-    if (io.pl16) HIP_TRY(c, launch_unpack_pl16(c->d_pl[s], c->d_col, c->d_lut, N, n_seq, n, c->d_lk[s], s_k));
     const bool need_single = io.single || io.gpp;
     const bool need_status = io.status || called;
-    HIP_TRY(c, launch_engine(c, n, c->d_lk[s], io.flags ? c->d_flags[s] : nullptr, c->d_post[s],
-                             need_single ? c->d_single[s] : nullptr, need_status ? c->d_status[s] : nullptr, s_k));
-    if (called)
-      HIP_TRY(c, launch_phred_call(c->d_post[s], c->d_single[s], c->d_status[s], c->d_seq, N, n_seq, n, c->d_gpp[s],
-                                   c->d_fpp[s], c->d_fgt[s], s_k));
+    bool fused = false;
+    if (called && !io.post && !io.single) {
+      CallIO cio;
+      cio.pl = io.pl16 ? c->d_pl[s] : nullptr;
+      cio.lut = c->d_lut;
+      cio.col = c->d_col;
+      cio.seq = c->d_seq;
+      cio.gpp = io.gpp ? c->d_gpp[s] : nullptr;
+      cio.fpp = io.fpp ? c->d_fpp[s] : nullptr;
+      cio.fgt = io.fgt ? c->d_fgt[s] : nullptr;
+      cio.n_seq = n_seq;
+      hipError_t e = hipSuccess;
+      fused = launch_engine_fused(c, n, io.pl16 ? nullptr : c->d_lk[s], io.flags ? c->d_flags[s] : nullptr,
+                                  need_status ? c->d_status[s] : nullptr, cio, c->d_call[s], s_k, &e);
+      if (fused) HIP_TRY(c, e);
+    }
+    if (!fused) {
+      if (io.pl16) HIP_TRY(c, launch_unpack_pl16(c->d_pl[s], c->d_col, c->d_lut, N, n_seq, n, c->d_lk[s], s_k));
+      HIP_TRY(c, launch_engine(c, n, c->d_lk[s], io.flags ? c->d_flags[s] : nullptr, c->d_post[s],
+                               need_single ? c->d_single[s] : nullptr, need_status ? c->d_status[s] : nullptr, s_k));
+      if (called)
+        HIP_TRY(c, launch_phred_call(c->d_post[s], c->d_single[s], c->d_status[s], c->d_seq, N, n_seq, n, c->d_gpp[s],
+                                     c->d_fpp[s], c->d_fgt[s], s_k));
+    }
     HIP_TRY(c, hipEventRecord(c->ev_done[s], s_k));
     // copy out
     HIP_TRY(c, hipStreamWaitEvent(s_out, c->ev_done[s], 0));

@@ -378,6 +378,59 @@ int elim_block_threads(const famseq_model &m) {
   return m.n_members <= 10 ? 256 : 128;
 }
 
+// Text every generated kernel carries for the fused call path (SURVEY.md 8(f) rows N2 + N4): packed
+// integer PLs staged straight into the LDS rows (the reference's lk = pow(10, -|PL| / 10), file.cpp:588-590,
+// through the host-filled table; missing sample / unsequenced member = {1,1,1}, :565, :794-809) and the
+// drivers' per-sample outputs formed while the rows are stored: GPP / FPP = fabs(-10 log10 p), +inf ->
+// 99999 (file.cpp:696-745) and FGT = arg-max with strict '<' from -1 (family.cpp:636-665), gathered in
+// VCF column order.  A failed site's rows are NaN, which gives NaN Phred values and FGT -1 by itself.
+#define FS_PHRED_DEF(...) #__VA_ARGS__
+const char FS_PHRED_TEXT_[] =
+#include "phred_src.h"
+    ;
+#undef FS_PHRED_DEF
+const std::string kCallHelpers = std::string(R"(
+#ifndef FS_RCP
+#define FS_RCP(x) __builtin_amdgcn_rcp(x)
+#define FS_FREXP_MANT(x) __builtin_amdgcn_frexp_mant(x)
+#define FS_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
+#define FS_UMULHI(a, b) __umulhi(a, b)
+#endif
+)") + FS_PHRED_TEXT_ + std::string(R"(
+// The call path's arguments sit in one small struct in device memory behind a pointer that is null on the
+// plain path: its fields are fetched (scalar loads) only inside the stages that use them.  As ten more
+// kernel arguments they stayed live in SGPRs for the whole kernel and pushed the arithmetic into scratch.
+struct fs_call_args {
+  const unsigned short *pl;  // [n_sites][n_seq][3] packed PLs, or null: fp64 likelihood rows come in as usual
+  const double *lut;         // pow(10, -k / 10), k < 4096
+  const int *col, *seq;      // member -> VCF column or -1; VCF column -> member
+  double *gpp, *fpp;         // [n_sites][n_seq][3], either may be null
+  signed char *fgt;          // [n_sites][n_seq] or null
+  int n_seq;
+  unsigned magic_w, magic_n;  // 2^32 / (3 n_seq) + 1, 2^32 / n_seq + 1: e / d = umulhi(e, magic) for e < 2^16
+};
+#define STAGE_IN_PL() { const int n_seq = call_g->n_seq; const int *col_ = call_g->col; const double *lut_ = call_g->lut; \
+  const unsigned short *p_ = call_g->pl + site0 * n_seq * 3; \
+  for (int it_ = tid; it_ < ns * NMEM; it_ += BT) { const int s_ = it_ / NMEM, i_ = it_ - s_ * NMEM, c_ = col_[i_]; \
+    double v0_ = 1.0, v1_ = 1.0, v2_ = 1.0; \
+    if (c_ >= 0) { const unsigned short *q_ = p_ + (s_ * n_seq + c_) * 3; const unsigned a_ = q_[0], b_ = q_[1], d_ = q_[2]; \
+      if (!(a_ == 0xFFFFu && b_ == 0xFFFFu && d_ == 0xFFFFu)) { \
+        v0_ = a_ < 4096u ? lut_[a_] : 0.0; v1_ = b_ < 4096u ? lut_[b_] : 0.0; v2_ = d_ < 4096u ? lut_[d_] : 0.0; } } \
+    double *w_ = s_io + s_ * ROW + 3 * i_; w_[0] = v0_; w_[1] = v1_; w_[2] = v2_; } }
+#define STAGE_OUT_CALL(Gp) { const int w_ = 3 * call_g->n_seq; const unsigned mg_ = call_g->magic_w; const int *seq_ = call_g->seq; \
+  double *g_ = (Gp) + site0 * w_; \
+  for (int e = tid; e < ns * w_; e += BT) { const int s_ = (int)FS_UMULHI((unsigned)e, mg_), r_ = e - s_ * w_, k_ = (r_ * 171) >> 9; \
+    __builtin_nontemporal_store(fs_phred(s_io[s_ * ROW + 3 * seq_[k_] + (r_ - 3 * k_)]), g_ + e); } }
+#define STAGE_FGT(Gp) { const int n_seq = call_g->n_seq; const unsigned mg_ = call_g->magic_n; const int *seq_ = call_g->seq; \
+  signed char *g_ = (Gp) + site0 * n_seq; \
+  for (int it_ = tid; it_ < ns * n_seq; it_ += BT) { const int s_ = (int)FS_UMULHI((unsigned)it_, mg_), k_ = it_ - s_ * n_seq; \
+    const double *r_ = s_io + s_ * ROW + 3 * seq_[k_]; double best_ = -1; signed char pick_ = -1; \
+    for (int h_ = 0; h_ < 3; ++h_) if (best_ < r_[h_]) { best_ = r_[h_]; pick_ = (signed char)h_; } \
+    g_[it_] = pick_; } }
+)");
+// ... and the arguments that go with it, after the plain ones: all null / 0 on the plain path
+const char kCallArgs[] = ", const struct fs_call_args *__restrict__ call_g";
+
 // Statements of the single posterior (family.cpp:1426-1445) and of the shortcut vote (:767-789), the
 // same as in bn_kernel.hip; they read l<p>_<g> and tcf[], set single_fail / full, and (store) write
 // the normalised rows to row[].  Shared by every generated shell.
@@ -413,7 +466,7 @@ std::string single_posterior_statements(const famseq_model &m, bool flags_pass, 
 //                   BEFORE the single posterior takes over the row.
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
-                         bool chrx_loop, int row_doubles) {
+                         bool chrx_loop, int row_doubles, bool call_mode) {
   // ROW: the lane's LDS row, W3 doubles padded to an odd count (conflict-free ds_read_b64); a
   // generator may ask for more (spare slots it uses itself), odd again
   const int N = m.n_members, W3 = 3 * N, ROW = (row_doubles > 0 ? row_doubles : W3) | 1;
@@ -421,7 +474,10 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
   // pays while it does not spill (ped5: +14 %); beyond the limits below it spills and loses.
   int prefetch_max_n = regs_l ? 7 : 10;  // the register-resident shell already holds the row: less room
   if (const char *e = std::getenv("FAMSEQ_PREFETCH_MAXN")) prefetch_max_n = std::atoi(e);  // tuning aid
-  const bool prefetch = N <= prefetch_max_n;
+  // call_mode: the fused call path's form of the kernel (famseq_bn_call_batch): input packed PLs or fp64
+  // rows, outputs GPP / FPP / FGT / status only, arguments behind call_g; no prefetch (the kernel is
+  // paced by the logarithms of its outputs).  The plain form carries none of this: its code is unchanged.
+  const bool prefetch = N <= prefetch_max_n && !call_mode;
   // Where the next chunk's loads are issued: after the arithmetic (registers are free there, the
   // loads overlap the output phases), or — early — right after this chunk's rows went to LDS (a whole
   // chunk of time to land, but K2 * 4 registers live through the arithmetic).  Early measured no
@@ -486,13 +542,17 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "#define STAGE_PRE() { \\\n"
     << "  if (v16) { WALK16(s_io[a] = pre[k].x; s_io[a1] = pre[k].y) } \\\n"
     << "  else { WALK8(s_io[a] = ((double *)pre)[k]) } }\n";
+  if (call_mode)
+    s << "#define NMEM " << N << "\n" << kCallHelpers
+      << "#define STAGE_IN_ANY() { if (packed_in) { STAGE_IN_PL(); } else { STAGE_IN(lk_g); } }\n";
+
   if (!regs_l)
     for (int p = 0; p < N; ++p)
       for (int gt = 0; gt < 3; ++gt) s << "#define l" << p << "_" << gt << " lrow[" << 3 * p + gt << "]\n";
   s << "extern \"C\" __global__ __launch_bounds__(BT, " << min_waves << ") void " << entry
     << "(const double *__restrict__ lk_g,\n"
     << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
-    << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
+    << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc" << (call_mode ? kCallArgs : "") << ") {\n"
     << "  __shared__ double s_io[BT * ROW];  // one padded row per lane: conflict-free ds_read_b64\n"
     << "  __shared__ double s_tc[432];\n"
     << "  const int tid = threadIdx.x;\n"
@@ -509,6 +569,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  v2d pre[K2];  // (prefetch) this lane's share of the NEXT chunk, loaded ahead\n"
     << "  const bool v16 = (((unsigned long)lk_g | (unsigned long)post_g | (unsigned long)single_g) & 15) == 0;\n"
     << "  bool have_pre = false;\n"
+    << (call_mode ? "  const bool packed_in = call_g->pl != nullptr;  // fed with packed PLs (else fp64 rows)\n" : "")
     << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
     << "    const long site0 = ch * BT;\n"
     << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
@@ -522,7 +583,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
   } else {
-    s << "    STAGE_IN(lk_g);\n";
+    s << (call_mode ? "    STAGE_IN_ANY();\n" : "    STAGE_IN(lk_g);\n");
   }
   s << "    LDS_BARRIER();\n"
     << "    const int fl = (tid < ns && flags_g) ? (flags_g[site0 + tid] & 3) : 0;\n"
@@ -536,10 +597,10 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     single_pass(true, true);
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << "    LDS_BARRIER();\n"
-      << "    if (single_g) { STAGE_OUT(single_g); }\n"
+      << (call_mode ? "    if (call_g->gpp) { STAGE_OUT_CALL(call_g->gpp); }\n" : "    if (single_g) { STAGE_OUT(single_g); }\n")
       << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n"
       << "    if (full && !single_fail) {\n"
-      << "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;  // this lane's row in global memory\n"
+      << "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;  // this lane's row in global memory (fp64 input only)\n"
       << "      (void)lg;\n"
       << body
       << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
@@ -549,7 +610,8 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
     s
       << "    LDS_BARRIER();\n"
-      << "    STAGE_OUT(post_g);\n"
+      << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
+                    : "    STAGE_OUT(post_g);\n")
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
       << "  }\n}\n";
   } else {
@@ -581,20 +643,21 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     single_pass(false, true);  // now the single posterior may take the row over
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << "    LDS_BARRIER();\n"
-      << "    if (single_g) { STAGE_OUT(single_g); }\n"
+      << (call_mode ? "    if (call_g->gpp) { STAGE_OUT_CALL(call_g->gpp); }\n" : "    if (single_g) { STAGE_OUT(single_g); }\n")
       << "    LDS_BARRIER();  // single rows are stored; sites that ran the full computation overwrite theirs\n"
       << "    if (full && !single_fail) {\n"
       << "#pragma unroll\n      for (int k = 0; k < W3; ++k) row[k] = bn_fail ? kNaN : q[k];\n"
       << "    }\n"
       << "    LDS_BARRIER();\n"
-      << "    STAGE_OUT(post_g);\n"
+      << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
+                    : "    STAGE_OUT(post_g);\n")
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
       << "  }\n}\n";
   }
   return s.str();
 }
 
-std::string elim_source(const famseq_model &m, int variant) {
+std::string elim_source(const famseq_model &m, int variant, bool call_mode) {
   Graph g;
   std::string why;
   if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);
@@ -609,9 +672,9 @@ std::string elim_source(const famseq_model &m, int variant) {
   return kernel_shell(m, "famseq_elim",
                       "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families" +
                           (g.cut.empty() ? "" : ", conditioned on " + std::to_string(g.cut.size()) + " member(s)") +
-                          ", variant " + std::to_string(variant),
+                          ", variant " + std::to_string(variant) + (call_mode ? ", call path" : ""),
                       Emitter(m, g, variant < 2 ? variant : 2, /*scalar_t=*/variant >= 1).body(), bt, min_waves,
-                      /*regs_l=*/false, variant >= 3, /*chrx_loop=*/variant >= 1);
+                      /*regs_l=*/false, variant >= 3, /*chrx_loop=*/variant >= 1, 0, call_mode);
 }
 
 }  // namespace famseq

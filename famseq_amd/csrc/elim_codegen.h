@@ -17,14 +17,17 @@ int elim_conditioned_members(const famseq_model &m);
 // variant 0..kElimVariants-1: decreasing instruction-level parallelism / register pressure
 // (jit_pick_variant takes the first that does not spill)
 constexpr int kElimVariants = 4;
-std::string elim_source(const famseq_model &m, int variant);
+// call_mode: the fused call path's form (packed PLs or fp64 rows in; GPP / FPP / FGT / status out)
+std::string elim_source(const famseq_model &m, int variant, bool call_mode = false);
 int elim_block_threads(const famseq_model &m);
 
 // Shared shell of the generated kernels (see elim_codegen.cpp).
+extern const std::string kCallHelpers;  // fused call path: fs_phred, STAGE_IN_PL, STAGE_OUT_CALL, STAGE_FGT
+extern const char kCallArgs[];     // ... and the kernel arguments that go with them
 std::string single_posterior_statements(const famseq_model &m, bool flags_pass, bool store, bool fence_single);
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
-                         bool chrx_loop = false, int row_doubles = 0);
+                         bool chrx_loop = false, int row_doubles = 0, bool call_mode = false);
 
 }  // namespace famseq
 #endif

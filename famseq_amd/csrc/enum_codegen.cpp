@@ -607,6 +607,8 @@ int enumgen_block_threads(const famseq_model &m) {
   return m.n_members <= 10 ? 256 : 128;
 }
 
+bool enumgen_reads_global_rows(const famseq_model &m) { return enumgen_source(m, 0).find("lg[") != std::string::npos; }
+
 int enumgen_max_group_digits(const famseq_model &m) {
   int cap = 6;
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);
@@ -698,7 +700,7 @@ std::string grouped_shell(const famseq_model &m, const std::string &comment, con
 
 }  // namespace
 
-std::string enumgen_source(const famseq_model &m, int variant, int group_digits) {
+std::string enumgen_source(const famseq_model &m, int variant, int group_digits, bool call_mode) {
   int cap = 6;
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);  // tuning aid
   const Shape s = choose_shape(m, cap);
@@ -730,14 +732,16 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits)
   int min_waves = bt / 128;
   if (const char *e = std::getenv("FAMSEQ_LANE_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
   Gen gen(m, s, row_len, group_digits);
+  if (call_mode) what += ", call path";
   if (group > 1) {
+    if (call_mode) throw std::runtime_error("enumeration codegen: the lanes-per-site form has no call path");
     const std::string body = gen.body();
     return grouped_shell(m, what, body, gen.reduce_body(), bt, min_waves, variant >= 1, row_len, group);
   }
   // regs_l: LDS-resident likelihoods measured 17% slower.  variant 0: the members of the single
   // posterior overlap, 1: fenced one from the other (fewer registers)
   return kernel_shell(m, "famseq_enum_lane", what, gen.body(), bt, min_waves, /*regs_l=*/true, variant >= 1,
-                      /*chrx_loop=*/false, row_len);
+                      /*chrx_loop=*/false, row_len, call_mode);
 }
 
 }  // namespace famseq

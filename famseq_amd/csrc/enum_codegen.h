@@ -13,8 +13,11 @@ constexpr int kEnumVariants = 2;  // see elim_codegen.h
 // group_digits = d > 0: lanes-per-site mode for small batches — 3^d consecutive lanes share a site, each
 // taking one combination of the d outermost looped members' digits (d <= enumgen_max_group_digits)
 constexpr int kEnumMaxGroupDigits = 4;
-std::string enumgen_source(const famseq_model &m, int variant, int group_digits = 0);
+std::string enumgen_source(const famseq_model &m, int variant, int group_digits = 0, bool call_mode = false);
 int enumgen_max_group_digits(const famseq_model &m);
+// true when the one-lane-per-site kernel re-reads some members' likelihoods from the fp64 rows in global
+// memory inside its loops (wide pedigrees whose LDS row cannot hold them): such a kernel needs fp64 input
+bool enumgen_reads_global_rows(const famseq_model &m);
 int enumgen_sites_per_chunk(const famseq_model &m, int group_digits);  // sites a workgroup handles per chunk
 int enumgen_block_threads(const famseq_model &m);
 // One-line description of the lane kernel's tiling (which members are looped / unrolled).

@@ -14,7 +14,9 @@
 // kTileSites sites; inside a tile the element index is a 16-bit number, so site / member / genotype
 // come from two multiply-shift divisions (exact for n < 2^16, divisors <= 60: the launchers check
 // 3 * members <= 60) instead of the 64-bit integer divisions a flat index over n_sites * W3 costs.
-// phred_call is bound by its two fp64 log10 per element (VALU), unpack_pl16 by HBM.
+// phred_call is bound by its two fp64 logarithms per element (VALU; phred_src.h), unpack_pl16 by HBM.
+// Batches served by the generated kernels do both inside the posterior kernel (elim_codegen.cpp kCallHelpers);
+// these two remain for the compiled-in team kernel and the lanes-per-site mode.
 #include <hip/hip_runtime.h>
 
 #include "io_kernels.h"
@@ -57,10 +59,12 @@ __global__ __launch_bounds__(256) void unpack_pl16_kernel(const uint16_t *__rest
   }
 }
 
-__device__ __forceinline__ double phred(double p) {
-  const double q = -10 * log10(p);
-  return q == __builtin_inf() ? 99999.0 : fabs(q);
-}
+#define FS_RCP(x) __builtin_amdgcn_rcp(x)
+#define FS_FREXP_MANT(x) __builtin_amdgcn_frexp_mant(x)
+#define FS_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
+#define FS_PHRED_DEF(...) __VA_ARGS__
+#include "phred_src.h"
+__device__ __forceinline__ double phred(double p) { return fs_phred(p); }
 
 __global__ __launch_bounds__(256) void phred_call_kernel(const double *__restrict__ post, const double *__restrict__ single,
                                                          const uint8_t *__restrict__ status,

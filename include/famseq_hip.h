@@ -110,7 +110,8 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *   "chunk_sites"   host-staging chunk of famseq_bn_batch (0 = auto)
  *   "enum_impl"     which enumeration kernel serves FAMSEQ_ENGINE_ENUM: 0 = the team-per-site kernel
  *                   compiled into the library (any batch size, any pedigree, no compiler needed); 1 = the
- *                   kernel generated and compiled for this pedigree; -1 (default) = the generated kernel
+ *                   kernel generated and compiled for this pedigree, one lane per site unless "group_digits"
+ *                   says otherwise; -1 (default) = the generated kernel, lanes per site chosen by batch size,
  *                   for batches of >= "lane_min_sites" (256) sites when it can be built, the team kernel
  *                   otherwise (tiny calls never wait for a compile)
  *   "group_digits"  the generated kernel's lanes per site, 3^d: d = 0 one lane per site (large batches),
@@ -119,6 +120,8 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *                   members' genotypes; the group sums through LDS); -1 (default) = chosen per call from
  *                   the batch size.  At most the number of looped members of the pedigree's enumeration
  *                   (famseq_plan_json "enum_group_digits_max"; 0 for pedigrees of up to 6 members)
+ *   "call_kernels"  1 = build the generated kernels' fused call-path forms now (famseq_bn_call_batch would on
+ *                   its first call)
  *   "engine"        FAMSEQ_ENGINE_ENUM (default) or FAMSEQ_ENGINE_ELIM; selecting ELIM generates the
  *                   kernel for this pedigree, compiles it with hipcc (cached on disk) and fails with
  *                   FAMSEQ_E_ARG on a pedigree whose loops need more than three conditioned members
@@ -173,7 +176,11 @@ int famseq_bn_batch_device_sharded(famseq_ctx *const *ctxs, int n_ctx, const int
  *   gpp, fpp [n_sites][n_seq][3]  fabs(-10*log10(p)) of the single / BN posterior, +inf -> 99999
  *                                 (file.cpp:696-745); NaN where the site failed
  *   fgt      [n_sites][n_seq]     arg-max genotype 0/1/2 (family.cpp:636-665), -1 where the site failed
- * Any of gpp / fpp / fgt / status may be NULL.  Blocking; chunks are pipelined like famseq_bn_batch. */
+ * Any of gpp / fpp / fgt / status may be NULL.  Blocking; chunks are pipelined like famseq_bn_batch.
+ * Batches served by a generated kernel run ONE kernel per chunk — its call-path form unpacks the PLs into
+ * the LDS rows and turns the posterior rows into GPP / FPP / FGT while storing them; the fp64 likelihoods and
+ * posteriors never exist in HBM.  The compiled-in team kernel and the lanes-per-site mode (tiny batches)
+ * keep the separate unpack / posterior / Phred stages; both ways give the same bits. */
 int famseq_bn_call_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, const uint16_t *pl16,
                          const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, double *gpp, double *fpp,
                          int8_t *fgt, uint8_t *status);

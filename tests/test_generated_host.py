@@ -31,6 +31,19 @@ static idx3_ threadIdx{0}, blockIdx{0}, gridDim{1};
 """
 
 
+# the call-path forms use three device builtins and __umulhi: host equivalents
+SHIM_CALL = r"""
+#include <cmath>
+#define FS_RCP(x) (1.0 / (x))
+static inline double fs_mant_(double x) { int e; return std::frexp(x, &e); }
+static inline int fs_exp_(double x) { int e; std::frexp(x, &e); return e; }
+#define FS_FREXP_MANT(x) fs_mant_(x)
+#define FS_FREXP_EXP(x) fs_exp_(x)
+#define FS_UMULHI(a, b) ((unsigned)(((unsigned long long)(a) * (unsigned long long)(b)) >> 32))
+#define __device__
+#define __forceinline__ inline
+"""
+
 # Lanes-per-site kernels need their G lanes to meet at the workgroup barriers: the lanes are host
 # threads here (thread-local threadIdx, the `static` LDS arrays shared), the barrier a pthread barrier.
 SHIM_THREADS = r"""
@@ -71,7 +84,7 @@ def host_source(src: str, threads=False) -> str:
         src = re.sub(r'asm volatile\(""[^\n;]*\);', "", src)
         assert "asm" not in src
         return src
-    src = src.replace("#include <hip/hip_runtime.h>", SHIM)
+    src = src.replace("#include <hip/hip_runtime.h>", SHIM + (SHIM_CALL if "fs_call_args" in src else ""))
     src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() (void)0", src)
     src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "")
     src = src.replace("__attribute__((address_space(3)))", "")
@@ -167,6 +180,21 @@ def build_host_kernel(model, kind, tmp_path, monkeypatch):
         fn.restype = None
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_double]
         return fn
+    if kind in ("lane_call", "elim_call"):  # the fused call-path forms
+        ctx.set_option("call_kernels", 1)
+        plan = ctx.plan()
+        obj, entry = ((plan["enum_lane_call_code_object"], "famseq_enum_lane") if kind == "lane_call"
+                      else (plan["elim_call_code_object"], "famseq_elim"))
+        ctx.close()
+        src = open(obj[:-6] + ".hip").read()
+        assert "call path" in src.splitlines()[0] and "#define BT 1\n" in src
+        cpp, so = str(cache / "k.cpp"), str(cache / "k.so")
+        open(cpp, "w").write(host_source(src))
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-w", "-shared", "-fPIC", "-o", so, cpp])
+        fn = getattr(C.CDLL(so), entry)
+        fn.restype = None
+        fn.argtypes = [C.c_void_p] * 5 + [C.c_long, C.c_void_p, C.c_double, C.c_void_p]
+        return fn
     if kind == "lane":
         ctx.set_option("enum_impl", 1)
         obj, entry = ctx.plan()["enum_lane_code_object"], "famseq_enum_lane"
@@ -261,3 +289,84 @@ def test_lanes_per_site_mode_matches_the_fixtures(case, d, tmp_path, monkeypatch
     assert np.array_equal(single[s_ok], case.single[:n][s_ok])
     np.testing.assert_allclose(post[ok], case.post[:n][ok], rtol=1e-12, atol=0)
     assert np.all(np.isnan(post[~ok]))
+
+
+class CallArgs(C.Structure):  # struct fs_call_args of the generated source
+    _fields_ = [("pl", C.c_void_p), ("lut", C.c_void_p), ("col", C.c_void_p), ("seq", C.c_void_p), ("gpp", C.c_void_p),
+                ("fpp", C.c_void_p), ("fgt", C.c_void_p), ("n_seq", C.c_int32), ("magic_w", C.c_uint32), ("magic_n", C.c_uint32)]
+
+
+def host_phred(p):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = -10 * np.log10(p)
+    return np.where(np.isposinf(q), 99999.0, np.abs(q))
+
+
+CALL_CASES = [c for c in CASES if c.name in ("bn_vcf:fam01", "bn_synth:quad_mu0", "bn_synth:ped10_x", "bn_synth:ped5", "bn_lk:fam06")]
+
+
+@pytest.mark.parametrize("kind", ["lane_call", "elim_call"])
+@pytest.mark.parametrize("case", CALL_CASES, ids=[c.name for c in CALL_CASES])
+def test_call_path_forms_match_the_fixtures(case, kind, tmp_path, monkeypatch):
+    """The fused call-path form of both generated kernels on the host: fp64 rows in -> GPP / FPP / FGT in a
+    shuffled VCF column order, against fabs(-10 log10) of the fixtures' posteriors (failed sites: NaN and
+    -1); then the same sites as packed integer PLs (with a missing sample and a PL beyond the table)
+    against the fp64 input of the table's values: identical bits."""
+    import math
+
+    ped = case.pedigree()
+    model = fs.make_model(ped, **case.consts)
+    if kind == "elim_call":
+        probe = fs.Context(model, device=-1)
+        ok_ = probe.plan()["elim_supported"]
+        probe.close()
+        if not ok_:
+            pytest.skip("more loops than the sum-product engine conditions on")
+    fn = build_host_kernel(model, kind, tmp_path, monkeypatch)
+    n = ped.n
+    seq = np.nonzero(case.sequenced)[0][::-1].astype(np.int32).copy()
+    k = len(seq)
+    col = np.full(20, -1, np.int32)
+    col[seq] = np.arange(k)
+    lut = np.array([math.pow(10.0, -i / 10.0) for i in range(4096)])
+    tc = np.ascontiguousarray(factor_tables(model))
+
+    def run(lk=None, pl=None, flags=None):
+        S = len(flags)
+        gpp, fpp = np.full((S, k, 3), -7.0), np.full((S, k, 3), -7.0)
+        fgt, st = np.full((S, k), 9, np.int8), np.full(S, 77, np.uint8)
+        a = CallArgs(None if pl is None else pl.ctypes.data, lut.ctypes.data, col.ctypes.data, seq.ctypes.data, gpp.ctypes.data,
+                     fpp.ctypes.data, fgt.ctypes.data, k, 0xFFFFFFFF // (3 * k) + 1, 0xFFFFFFFF // k + 1)
+        keep = misaligned(lk.shape) if lk is not None else None
+        if lk is not None:
+            keep[...] = lk
+        fn(None if lk is None else keep.ctypes.data, flags.ctypes.data, None, None, st.ctypes.data, S, tc.ctypes.data,
+           float(model.lc), C.addressof(a))
+        return gpp, fpp, fgt, st
+
+    flags = np.ascontiguousarray(case.flags, np.uint8)
+    gpp, fpp, fgt, st = run(lk=case.lk, flags=flags)
+    assert np.array_equal(st, case.status)
+    ok, s_ok = (st & 3) == 0, (st & 3) != 1
+    np.testing.assert_allclose(gpp[s_ok], host_phred(case.single[s_ok][:, seq]), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(fpp[ok], host_phred(case.post[ok][:, seq]), rtol=1e-9, atol=1e-9)
+    assert np.array_equal(fgt[ok], fs.call_genotypes(case.post[ok][:, seq]).reshape(-1, k))
+    assert np.all(np.isnan(fpp[~ok])) and np.all(fgt[~ok] == -1) and np.all(np.isnan(gpp[~s_ok]))
+    if kind == "lane_call" and "lg[" in open(tmp_path / ("cache_" + kind) / "k.cpp").read():
+        return  # this pedigree's lane kernel re-reads fp64 rows from global memory: the library feeds it fp64 rows only
+    rng = np.random.RandomState(3)
+    S = 40
+    pl = rng.randint(0, 300, size=(S, k, 3)).astype(np.uint16)
+    pl[np.arange(S)[:, None], np.arange(k)[None, :], rng.randint(0, 3, size=(S, k))] = 0
+    pl[::5, 0] = 0xFFFF
+    pl[::7, k - 1] = [0, 5000, 65534]
+    table = np.append(lut, 0.0)
+    lk2 = np.ones((S, n, 3))
+    for j, mbr in enumerate(seq):
+        v = table[np.minimum(pl[:, j].astype(np.int64), 4096)]
+        v[np.all(pl[:, j] == 0xFFFF, axis=1)] = 1.0
+        lk2[:, mbr] = v
+    fl2 = rng.randint(0, 4, S).astype(np.uint8)
+    a, b = run(lk=lk2, flags=fl2), run(pl=pl, flags=fl2)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
