@@ -409,24 +409,37 @@ struct fs_call_args {
   int n_seq;
   unsigned magic_w, magic_n;  // 2^32 / (3 n_seq) + 1, 2^32 / n_seq + 1: e / d = umulhi(e, magic) for e < 2^16
 };
-#define STAGE_IN_PL() { const int n_seq = call_g->n_seq; const int *col_ = call_g->col; const double *lut_ = call_g->lut; \
-  const unsigned short *p_ = call_g->pl + site0 * n_seq * 3; \
-  for (int it_ = tid; it_ < ns * NMEM; it_ += BT) { const int s_ = it_ / NMEM, i_ = it_ - s_ * NMEM, c_ = col_[i_]; \
+// packed PLs of the chunk -> likelihood rows in LDS: one (site, member) item per lane and step.  Whole chunks
+// take the unrolled, predicate-free walk (all of a lane's loads in flight together); the table look-ups
+// depend on the PLs, so that is two memory latencies per chunk instead of two per member.
+#define PL_ITEM(it_) { const int s_ = (it_) / NMEM, i_ = (it_) - s_ * NMEM, c_ = s_col[i_]; \
     double v0_ = 1.0, v1_ = 1.0, v2_ = 1.0; \
     if (c_ >= 0) { const unsigned short *q_ = p_ + (s_ * n_seq + c_) * 3; const unsigned a_ = q_[0], b_ = q_[1], d_ = q_[2]; \
       if (!(a_ == 0xFFFFu && b_ == 0xFFFFu && d_ == 0xFFFFu)) { \
         v0_ = a_ < 4096u ? lut_[a_] : 0.0; v1_ = b_ < 4096u ? lut_[b_] : 0.0; v2_ = d_ < 4096u ? lut_[d_] : 0.0; } } \
-    double *w_ = s_io + s_ * ROW + 3 * i_; w_[0] = v0_; w_[1] = v1_; w_[2] = v2_; } }
-#define STAGE_OUT_CALL(Gp) { const int w_ = 3 * call_g->n_seq; const unsigned mg_ = call_g->magic_w; const int *seq_ = call_g->seq; \
-  double *g_ = (Gp) + site0 * w_; \
-  for (int e = tid; e < ns * w_; e += BT) { const int s_ = (int)FS_UMULHI((unsigned)e, mg_), r_ = e - s_ * w_, k_ = (r_ * 171) >> 9; \
-    __builtin_nontemporal_store(fs_phred(s_io[s_ * ROW + 3 * seq_[k_] + (r_ - 3 * k_)]), g_ + e); } }
-#define STAGE_FGT(Gp) { const int n_seq = call_g->n_seq; const unsigned mg_ = call_g->magic_n; const int *seq_ = call_g->seq; \
-  signed char *g_ = (Gp) + site0 * n_seq; \
+    double *w_ = s_io + s_ * ROW + 3 * i_; w_[0] = v0_; w_[1] = v1_; w_[2] = v2_; }
+#define STAGE_IN_PL() { const int n_seq = call_g->n_seq; const double *lut_ = call_g->lut; \
+  const unsigned short *p_ = call_g->pl + site0 * n_seq * 3; \
+  if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) PL_ITEM(tid + j_ * BT) } \
+  else { for (int it_ = tid; it_ < ns * NMEM; it_ += BT) PL_ITEM(it_) } }
+// The lane's row holds probabilities (single or BN posterior, NaN where the site failed): turn it in place
+// into what is printed, fabs(-10 log10 p), and note the arg-max genotype of every member (strict '<' from
+// -1: ties to the lower genotype, NaN rows give -1).  3 N independent logarithms per lane: plenty of ILP.
+#define ROW_TO_CALL() { _Pragma("unroll") for (int p_ = 0; p_ < NMEM; ++p_) { \
+    const double d0_ = row[3 * p_], d1_ = row[3 * p_ + 1], d2_ = row[3 * p_ + 2]; \
+    signed char pk_ = -1; double bs_ = -1; \
+    if (bs_ < d0_) { bs_ = d0_; pk_ = 0; } if (bs_ < d1_) { bs_ = d1_; pk_ = 1; } if (bs_ < d2_) { bs_ = d2_; pk_ = 2; } \
+    s_fgt[tid * NMEM + p_] = pk_; \
+    row[3 * p_] = fs_phred(d0_); row[3 * p_ + 1] = fs_phred(d1_); row[3 * p_ + 2] = fs_phred(d2_); } }
+// rows -> [site][VCF column][genotype], coalesced; FGT likewise from the byte table
+#define CALL_ELEM(e_) { const int s_ = (int)FS_UMULHI((unsigned)(e_), mg_), r_ = (e_) - s_ * w_, k_ = (r_ * 171) >> 9; \
+    __builtin_nontemporal_store(s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)], g_ + (e_)); }
+#define STAGE_OUT_CALL(Gp) { const int w_ = 3 * call_g->n_seq; const unsigned mg_ = call_g->magic_w; double *g_ = (Gp) + site0 * w_; \
+  if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < 3 * NMEM; ++j_) if (j_ < w_) CALL_ELEM(tid + j_ * BT) } \
+  else { for (int e = tid; e < ns * w_; e += BT) CALL_ELEM(e) } }
+#define STAGE_FGT(Gp) { const int n_seq = call_g->n_seq; const unsigned mg_ = call_g->magic_n; signed char *g_ = (Gp) + site0 * n_seq; \
   for (int it_ = tid; it_ < ns * n_seq; it_ += BT) { const int s_ = (int)FS_UMULHI((unsigned)it_, mg_), k_ = it_ - s_ * n_seq; \
-    const double *r_ = s_io + s_ * ROW + 3 * seq_[k_]; double best_ = -1; signed char pick_ = -1; \
-    for (int h_ = 0; h_ < 3; ++h_) if (best_ < r_[h_]) { best_ = r_[h_]; pick_ = (signed char)h_; } \
-    g_[it_] = pick_; } }
+    g_[it_] = s_fgt[s_ * NMEM + s_seq[k_]]; } }
 )");
 // ... and the arguments that go with it, after the plain ones: all null / 0 on the plain path
 const char kCallArgs[] = ", const struct fs_call_args *__restrict__ call_g";
@@ -569,7 +582,11 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  v2d pre[K2];  // (prefetch) this lane's share of the NEXT chunk, loaded ahead\n"
     << "  const bool v16 = (((unsigned long)lk_g | (unsigned long)post_g | (unsigned long)single_g) & 15) == 0;\n"
     << "  bool have_pre = false;\n"
-    << (call_mode ? "  const bool packed_in = call_g->pl != nullptr;  // fed with packed PLs (else fp64 rows)\n" : "")
+    << (call_mode ? "  const bool packed_in = call_g->pl != nullptr;  // fed with packed PLs (else fp64 rows)\n"
+                    "  __shared__ int s_col[NMEM], s_seq[NMEM];  // member -> VCF column or -1; VCF column -> member\n"
+                    "  __shared__ signed char s_fgt[BT * NMEM];  // arg-max genotype of every member of every site of the chunk\n"
+                    "  for (int i = tid; i < NMEM; i += BT) { s_col[i] = call_g->col[i]; s_seq[i] = i < call_g->n_seq ? call_g->seq[i] : 0; }\n"
+                  : "")
     << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
     << "    const long site0 = ch * BT;\n"
     << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
@@ -596,6 +613,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     s << "    LDS_BARRIER();  // every lane holds its row in registers: the rows become the output stage\n";
     single_pass(true, true);
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
+      << (call_mode ? "    ROW_TO_CALL();  // the single posterior as printed (GPP) and its arg-max (FGT of shortcut sites)\n" : "")
       << "    LDS_BARRIER();\n"
       << (call_mode ? "    if (call_g->gpp) { STAGE_OUT_CALL(call_g->gpp); }\n" : "    if (single_g) { STAGE_OUT(single_g); }\n")
       << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n"
@@ -604,6 +622,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       << "      (void)lg;\n"
       << body
       << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
+      << (call_mode ? "      ROW_TO_CALL();  // the BN posterior as printed (FPP) and the genotype call\n" : "")
       << "    }\n";
     if (prefetch && !early)
       s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
@@ -642,11 +661,13 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       << "    if (have_pre) { PREFETCH(lk_g); }\n";
     single_pass(false, true);  // now the single posterior may take the row over
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
+      << (call_mode ? "    ROW_TO_CALL();  // the single posterior as printed (GPP) and its arg-max (FGT of shortcut sites)\n" : "")
       << "    LDS_BARRIER();\n"
       << (call_mode ? "    if (call_g->gpp) { STAGE_OUT_CALL(call_g->gpp); }\n" : "    if (single_g) { STAGE_OUT(single_g); }\n")
       << "    LDS_BARRIER();  // single rows are stored; sites that ran the full computation overwrite theirs\n"
       << "    if (full && !single_fail) {\n"
       << "#pragma unroll\n      for (int k = 0; k < W3; ++k) row[k] = bn_fail ? kNaN : q[k];\n"
+      << (call_mode ? "      ROW_TO_CALL();  // the BN posterior as printed (FPP) and the genotype call\n" : "")
       << "    }\n"
       << "    LDS_BARRIER();\n"
       << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"

@@ -718,7 +718,8 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
       if (m.mother[p] >= 0 && (s.upos[m.mother[p]] < 0 || s.upos[m.father[p]] < 0)) ++looped_tables;
     const int used = 6 * (int)s.outer.size() <= row_len ? 6 * (int)s.outer.size() : 3 * (int)s.outer.size();
     const int want = (used + 3 * looped_tables) | 1;
-    const int fit = ((160 * 1024 / 2 - 432 * 8) / (bt * 8) - 1) | 1;  // odd, two workgroups per CU
+    // odd, two workgroups per CU (the call-path form also keeps a byte per member and lane, and two small tables)
+    const int fit = ((160 * 1024 / 2 - 432 * 8 - (call_mode ? bt * m.n_members + 256 : 0)) / (bt * 8) - 1) | 1;
     if (want > row_len) row_len = std::min(want, std::max(row_len, fit));
   }
   int group = 1;

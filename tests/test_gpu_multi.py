@@ -31,10 +31,10 @@ def test_device_resident_sharded_entry():
 
     c, lk, flags = _ped10_batch(3001)
     model = fs.make_model(c.pedigree())
-    one = fs.Context(model)
+    one = fs.Context(model, enum_impl=1)  # one kernel on both sides: same bits
     ref = one.bn_batch(lk, flags)
     one.close()
-    ctxs = [fs.Context(model) for _ in range(3)]
+    ctxs = [fs.Context(model, enum_impl=1) for _ in range(3)]
     dev = torch.device("cuda", 0)
     cuts = [fs.shard.site_range(len(lk), r, 3) for r in range(3)]
     d_lk = [torch.from_numpy(lk[a:b]).to(dev) for a, b in cuts]
