@@ -355,22 +355,17 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
 // returns false when this batch goes through the separate stages instead (team kernel, lanes-per-site
 // mode, or a lane kernel that re-reads fp64 rows from global memory while the input is packed).
 bool launch_engine_fused(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, uint8_t *d_status,
-                         CallIO io, CallIO *d_io, hipStream_t stream, hipError_t *err) {
+                         bool packed_in, const CallIO *d_io, hipStream_t stream, hipError_t *err) {
   const bool elim = c->engine == FAMSEQ_ENGINE_ELIM;
   if (!elim) {
     const bool want_lane = c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites);
     if (!want_lane || pick_group_digits(c, n_sites) != 0) return false;
-    if (io.pl) {
+    if (packed_in) {
       if (c->lane_reads_rows < 0) c->lane_reads_rows = enumgen_reads_global_rows(c->model) ? 1 : 0;
       if (c->lane_reads_rows) return false;
     }
   }
   if (!load_call_kernel(c, elim)) return false;
-  // e / d for e < 2^16, d <= 60 as the high word of e * (2^32 / d + 1): exact (io_kernels.hip)
-  io.magic_w = 0xFFFFFFFFu / uint32_t(3 * io.n_seq) + 1;
-  io.magic_n = 0xFFFFFFFFu / uint32_t(io.n_seq) + 1;
-  *err = hipMemcpyAsync(d_io, &io, sizeof io, hipMemcpyHostToDevice, stream);  // pageable source: staged before it returns
-  if (*err != hipSuccess) return true;
   if (!elim) c->last_group_digits = 0;
   *err = launch_generated(c, elim ? c->elim_call.fn : c->lane_call.fn, elim ? elim_block_threads(c->model) : enumgen_block_threads(c->model),
                           elim ? c->elim_call_blocks_per_cu : c->lane_call_blocks_per_cu, n_sites, d_lk, d_flags, nullptr, nullptr,
@@ -652,6 +647,26 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
     HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_lut), lut.size() * sizeof(double)));
     HIP_TRY(c, hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
   }
+  if (called) {
+    // The generated kernels' call-path arguments (struct fs_call_args) depend on the slot only, not on the
+    // chunk: written once per call, synchronously (nothing of an earlier call is in flight any more), so
+    // that no asynchronous copy ever reads host memory that has gone out of scope.
+    for (int s = 0; s < famseq_ctx::kSlots; ++s) {
+      CallIO cio;
+      cio.pl = io.pl16 ? c->d_pl[s] : nullptr;
+      cio.lut = c->d_lut;
+      cio.col = c->d_col;
+      cio.seq = c->d_seq;
+      cio.gpp = io.gpp ? c->d_gpp[s] : nullptr;
+      cio.fpp = io.fpp ? c->d_fpp[s] : nullptr;
+      cio.fgt = io.fgt ? c->d_fgt[s] : nullptr;
+      cio.n_seq = n_seq;
+      // e / d for e < 2^16, d <= 60 as the high word of e * (2^32 / d + 1): exact (io_kernels.hip)
+      cio.magic_w = 0xFFFFFFFFu / uint32_t(3 * n_seq) + 1;
+      cio.magic_n = 0xFFFFFFFFu / uint32_t(n_seq) + 1;
+      HIP_TRY(c, hipMemcpy(c->d_call[s], &cio, sizeof cio, hipMemcpyHostToDevice));
+    }
+  }
   // From here on copies into the caller's buffers may be in flight: an error must not return
   // before both streams have drained.
   const int rc = run_chunks(c, n_sites, io, n_seq, chunk);
@@ -687,18 +702,9 @@ int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int6
     const bool need_status = io.status || called;
     bool fused = false;
     if (called && !io.post && !io.single) {
-      CallIO cio;
-      cio.pl = io.pl16 ? c->d_pl[s] : nullptr;
-      cio.lut = c->d_lut;
-      cio.col = c->d_col;
-      cio.seq = c->d_seq;
-      cio.gpp = io.gpp ? c->d_gpp[s] : nullptr;
-      cio.fpp = io.fpp ? c->d_fpp[s] : nullptr;
-      cio.fgt = io.fgt ? c->d_fgt[s] : nullptr;
-      cio.n_seq = n_seq;
       hipError_t e = hipSuccess;
       fused = launch_engine_fused(c, n, io.pl16 ? nullptr : c->d_lk[s], io.flags ? c->d_flags[s] : nullptr,
-                                  need_status ? c->d_status[s] : nullptr, cio, c->d_call[s], s_k, &e);
+                                  need_status ? c->d_status[s] : nullptr, io.pl16 != nullptr, c->d_call[s], s_k, &e);
       if (fused) HIP_TRY(c, e);
     }
     if (!fused) {
