@@ -553,8 +553,15 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
              std::to_string(enumgen_max_group_digits(c->model)) + ",\"enum_group_digits_last\":" +
              std::to_string(c->last_group_digits) + ",\"enum_group_code_objects\":[";
   for (int d = 1; d <= kEnumMaxGroupDigits; ++d) c->json += std::string(d > 1 ? "," : "") + "\"" + json_str(c->grp[d].path) + "\"";
+  if (c->lane_reads_rows < 0) {
+    try {
+      c->lane_reads_rows = enumgen_reads_global_rows(c->model) ? 1 : 0;
+    } catch (const std::exception &) {
+      c->lane_reads_rows = 0;
+    }
+  }
   c->json += "],\"enum_lane_call_code_object\":\"" + json_str(c->lane_call.path) + "\",\"elim_call_code_object\":\"" +
-             json_str(c->elim_call.path) + "\"}";
+             json_str(c->elim_call.path) + "\",\"enum_lane_call_reads_rows\":" + std::to_string(c->lane_reads_rows) + "}";
   return c->json.c_str();
 }
 

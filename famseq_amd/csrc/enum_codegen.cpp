@@ -607,7 +607,11 @@ int enumgen_block_threads(const famseq_model &m) {
   return m.n_members <= 10 ? 256 : 128;
 }
 
-bool enumgen_reads_global_rows(const famseq_model &m) { return enumgen_source(m, 0).find("lg[") != std::string::npos; }
+// (asked of the call-path form: its LDS row has less room than the plain form's, so it may re-read members
+// the plain form keeps in LDS — and it is the form that can be fed packed PLs, with no fp64 rows to read)
+bool enumgen_reads_global_rows(const famseq_model &m) {
+  return enumgen_source(m, 0, 0, /*call_mode=*/true).find("lg[") != std::string::npos;
+}
 
 int enumgen_max_group_digits(const famseq_model &m) {
   int cap = 6;

@@ -15,8 +15,9 @@ constexpr int kEnumVariants = 2;  // see elim_codegen.h
 constexpr int kEnumMaxGroupDigits = 4;
 std::string enumgen_source(const famseq_model &m, int variant, int group_digits = 0, bool call_mode = false);
 int enumgen_max_group_digits(const famseq_model &m);
-// true when the one-lane-per-site kernel re-reads some members' likelihoods from the fp64 rows in global
-// memory inside its loops (wide pedigrees whose LDS row cannot hold them): such a kernel needs fp64 input
+// true when the call-path form of the one-lane-per-site kernel re-reads some members' likelihoods from the
+// fp64 rows in global memory inside its loops (wide pedigrees whose LDS row cannot hold them): such a kernel
+// must be given fp64 input (lk_g non-null), never packed PLs
 bool enumgen_reads_global_rows(const famseq_model &m);
 int enumgen_sites_per_chunk(const famseq_model &m, int group_digits);  // sites a workgroup handles per chunk
 int enumgen_block_threads(const famseq_model &m);

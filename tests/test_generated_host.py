@@ -8,6 +8,7 @@ GENERATORS (indexing, tables, accumulation order, status rules); it is not a pro
 in famseq_amd/ can run this way, and the GPU parity tests remain the check of what ships.
 """
 import ctypes as C
+import os
 import re
 import subprocess
 
@@ -370,3 +371,30 @@ def test_call_path_forms_match_the_fixtures(case, kind, tmp_path, monkeypatch):
     a, b = run(lk=lk2, flags=fl2), run(pl=pl, flags=fl2)
     for x, y in zip(a, b):
         assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_packed_input_is_refused_to_a_kernel_that_rereads_fp64_rows(tmp_path, monkeypatch):
+    """The call-path form of a wide pedigree's lane kernel can have less LDS room than the plain form and
+    then re-reads some members' likelihoods from the fp64 rows in global memory (`lg[...]`).  Such a kernel
+    must never be fed packed PLs (there are no fp64 rows then: a null pointer on the GPU).  The library's
+    answer to "does it re-read" has to describe the CALL form — soak seed 10 is a pedigree where the two
+    forms differ (found as a GPU fault in round 2)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _soak import soak_pedigree
+
+    monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
+    monkeypatch.setenv("FAMSEQ_KEEP_SRC", "1")
+    seen = set()
+    for seed in (2, 8, 10):
+        _, ped, mu = soak_pedigree(seed)
+        ctx = fs.Context(fs.make_model(ped, mrate=mu), device=-1)
+        ctx.set_option("enum_impl", 1)
+        ctx.set_option("call_kernels", 1)
+        plan = ctx.plan()
+        ctx.close()
+        call_src = open(plan["enum_lane_call_code_object"][:-6] + ".hip").read()
+        assert plan["enum_lane_call_reads_rows"] == int("lg[" in call_src), seed
+        seen.add(plan["enum_lane_call_reads_rows"])
+    assert seen == {0, 1}
