@@ -670,7 +670,7 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
       cio.n_seq = n_seq;
       // e / d for e < 2^16, d <= 60 as the high word of e * (2^32 / d + 1): exact (io_kernels.hip)
       cio.magic_w = 0xFFFFFFFFu / uint32_t(3 * n_seq) + 1;
-      cio.magic_n = 0xFFFFFFFFu / uint32_t(n_seq) + 1;
+      cio.magic_n = n_seq > 1 ? 0xFFFFFFFFu / uint32_t(n_seq) + 1 : 0;  // one column: the kernel divides by 1 itself
       HIP_TRY(c, hipMemcpy(c->d_call[s], &cio, sizeof cio, hipMemcpyHostToDevice));
     }
   }

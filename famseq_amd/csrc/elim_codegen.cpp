@@ -407,7 +407,7 @@ struct fs_call_args {
   double *gpp, *fpp;         // [n_sites][n_seq][3], either may be null
   signed char *fgt;          // [n_sites][n_seq] or null
   int n_seq;
-  unsigned magic_w, magic_n;  // 2^32 / (3 n_seq) + 1, 2^32 / n_seq + 1: e / d = umulhi(e, magic) for e < 2^16
+  unsigned magic_w, magic_n;  // 2^32 / (3 n_seq) + 1, 2^32 / n_seq + 1: e / d = umulhi(e, magic) for e < 2^16; magic_n = 0 when n_seq = 1
 };
 // packed PLs of the chunk -> likelihood rows in LDS: one (site, member) item per lane and step.  Whole chunks
 // take the unrolled, predicate-free walk (all of a lane's loads in flight together); the table look-ups
@@ -438,7 +438,7 @@ struct fs_call_args {
   if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < 3 * NMEM; ++j_) if (j_ < w_) CALL_ELEM(tid + j_ * BT) } \
   else { for (int e = tid; e < ns * w_; e += BT) CALL_ELEM(e) } }
 #define STAGE_FGT(Gp) { const int n_seq = call_g->n_seq; const unsigned mg_ = call_g->magic_n; signed char *g_ = (Gp) + site0 * n_seq; \
-  for (int it_ = tid; it_ < ns * n_seq; it_ += BT) { const int s_ = (int)FS_UMULHI((unsigned)it_, mg_), k_ = it_ - s_ * n_seq; \
+  for (int it_ = tid; it_ < ns * n_seq; it_ += BT) { const int s_ = mg_ ? (int)FS_UMULHI((unsigned)it_, mg_) : it_, k_ = it_ - s_ * n_seq; \
     g_[it_] = s_fgt[s_ * NMEM + s_seq[k_]]; } }
 )");
 // ... and the arguments that go with it, after the plain ones: all null / 0 on the plain path

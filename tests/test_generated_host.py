@@ -398,3 +398,117 @@ def test_packed_input_is_refused_to_a_kernel_that_rereads_fp64_rows(tmp_path, mo
         assert plan["enum_lane_call_reads_rows"] == int("lg[" in call_src), seed
         seen.add(plan["enum_lane_call_reads_rows"])
     assert seen == {0, 1}
+
+
+def _threaded_call_kernel(model, elim, bt, cache, monkeypatch):
+    """Call-path form generated for `bt` lanes per workgroup, its lanes as host threads (the workgroup
+    barrier a pthread barrier, LDS the shared statics)."""
+    for k, v in dict(FAMSEQ_KERNEL_CACHE=str(cache), FAMSEQ_KEEP_SRC="1", FAMSEQ_LANE_BT=str(bt), FAMSEQ_ELIM_BT=str(bt),
+                     FAMSEQ_LANE_MINWAVES="1").items():
+        monkeypatch.setenv(k, v)
+    ctx = fs.Context(model, device=-1)
+    ctx.set_option("call_kernels", 1)
+    plan = ctx.plan()
+    ctx.close()
+    obj, entry = ((plan["elim_call_code_object"], "famseq_elim") if elim else (plan["enum_lane_call_code_object"], "famseq_enum_lane"))
+    src = open(obj[:-6] + ".hip").read()
+    reads_rows = "lg[" in src
+    shim = SHIM_THREADS.replace("#define famseq_enum_lane famseq_enum_lane_one_thread", "#define %s kernel_one_thread_" % entry)
+    shim += SHIM_CALL + "#define __builtin_amdgcn_ballot_w64(p) ((unsigned long)(p))\n"
+    src = src.replace("#include <hip/hip_runtime.h>", shim)
+    src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() pthread_barrier_wait(&wg_barrier_)", src)
+    src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "").replace("__attribute__((address_space(3)))", "")
+    src = re.sub(r'asm volatile\(""[^\n;]*\);', "", src.replace('extern "C" __global__', "static"))
+    src += """
+#undef %(e)s
+extern "C" void %(e)s(const double *lk, const unsigned char *fl, double *post, double *single, unsigned char *st, long n,
+                      const double *tc, double lc, const fs_call_args *call) {
+  pthread_barrier_init(&wg_barrier_, nullptr, BT);
+  std::vector<std::thread> lanes;
+  for (int t = 0; t < BT; ++t) lanes.emplace_back([=] { threadIdx.x = t; kernel_one_thread_(lk, fl, post, single, st, n, tc, lc, call); });
+  for (auto &l : lanes) l.join();
+  pthread_barrier_destroy(&wg_barrier_);
+}
+""" % dict(e=entry)
+    cpp, so = str(cache / ("t%d.cpp" % elim)), str(cache / ("t%d.so" % elim))
+    open(cpp, "w").write(src)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-w", "-shared", "-fPIC", "-pthread", "-o", so, cpp])
+    fn = getattr(C.CDLL(so), entry)
+    fn.restype = None
+    fn.argtypes = [C.c_void_p] * 5 + [C.c_long, C.c_void_p, C.c_double, C.c_void_p]
+    return fn, reads_rows
+
+
+@pytest.mark.parametrize("seed", [2, 10, 11, 15])
+def test_call_path_forms_as_whole_workgroups(seed, tmp_path, monkeypatch):
+    """The call-path staging is cooperative (a lane unpacks, converts and stores other lanes' sites), so
+    it is run here as a real workgroup of 8 host threads: soak pedigrees with unsequenced members, a
+    shuffled column order, ONE sequenced sample (seed 11: the column division by 1), whole and ragged
+    chunks, packed PLs with missing samples against fp64 rows of the table's values, and both against
+    the oracle."""
+    import math
+    import sys
+
+    import oracle
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _soak import soak_pedigree
+
+    rng, ped, mu = soak_pedigree(seed)
+    model = fs.make_model(ped, mrate=mu)
+    n = ped.n
+    seq = np.nonzero(ped.sequenced)[0].astype(np.int32)
+    rng.shuffle(seq)
+    k = len(seq)
+    col = np.full(20, -1, np.int32)
+    col[seq] = np.arange(k)
+    lut = np.array([math.pow(10.0, -i / 10.0) for i in range(4096)])
+    tc = np.ascontiguousarray(factor_tables(model))
+    probe = fs.Context(model, device=-1)
+    kinds = [False] + ([True] if probe.plan()["elim_supported"] else [])
+    probe.close()
+    for elim in kinds:
+        fn, reads_rows = _threaded_call_kernel(model, elim, 8, tmp_path, monkeypatch)
+        for S in (1, 8, 19):
+            pl = rng.randint(0, 400, size=(S, k, 3)).astype(np.uint16)
+            pl[np.arange(S)[:, None], np.arange(k)[None, :], rng.randint(0, 3, size=(S, k))] = 0
+            pl[rng.rand(S, k) < 0.1] = 0xFFFF
+            pl[rng.rand(S, k, 3) < 0.02] = 5000
+            flags = rng.randint(0, 4, S).astype(np.uint8)
+            table = np.append(lut, 0.0)
+            lk = np.ones((S, n, 3))
+            for j, mbr in enumerate(seq):
+                v = table[np.minimum(pl[:, j].astype(np.int64), 4096)]
+                v[np.all(pl[:, j] == 0xFFFF, axis=1)] = 1.0
+                lk[:, mbr] = v
+
+            def run(lk_in=None, pl_in=None):
+                gpp, fpp = np.full((S, k, 3), -7.0), np.full((S, k, 3), -7.0)
+                fgt, st = np.full((S, k), 9, np.int8), np.full(S, 77, np.uint8)
+                a = CallArgs(None if pl_in is None else pl_in.ctypes.data, lut.ctypes.data, col.ctypes.data, seq.ctypes.data,
+                             gpp.ctypes.data, fpp.ctypes.data, fgt.ctypes.data, k, 0xFFFFFFFF // (3 * k) + 1,
+                             0xFFFFFFFF // k + 1 if k > 1 else 0)
+                fn(None if lk_in is None else lk_in.ctypes.data, flags.ctypes.data, None, None, st.ctypes.data, S, tc.ctypes.data,
+                   float(model.lc), C.addressof(a))
+                return gpp, fpp, fgt, st
+
+            a = run(lk_in=np.ascontiguousarray(lk))
+            ref = oracle.OracleModel(ped.ids, ped.mids, ped.fids, ped.genders, ped.sequenced, mrate=mu).bn_batch(lk, flags, threads=2)
+            assert np.array_equal(a[3], ref[2]), (seed, elim, S)
+            ok, s_ok = (ref[2] & 3) == 0, (ref[2] & 3) != 1
+            np.testing.assert_allclose(a[0][s_ok], host_phred(ref[1][s_ok][:, seq]), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(a[1][ok], host_phred(ref[0][ok][:, seq]), rtol=1e-8, atol=1e-8)
+            # the call is the arg-max of the kernel's own posterior, which differs from the oracle's in the
+            # last bits: where the picks differ the two candidates must be a tie to rounding
+            want = fs.call_genotypes(ref[0][ok][:, seq]).reshape(-1, k)
+            rows = ref[0][ok][:, seq].reshape(-1, 3)
+            g_, w_ = a[2][ok].reshape(-1), want.reshape(-1)
+            assert np.all(g_ >= 0)
+            diff = g_ != w_
+            pa, pb = rows[np.arange(len(rows)), g_], rows[np.arange(len(rows)), w_]
+            assert np.all(np.abs(pa - pb)[diff] <= 1e-9 * pb[diff]), (seed, elim, S)
+            assert np.all(a[2][~ok] == -1) and np.all(np.isnan(a[1][~ok]))
+            if not reads_rows:
+                b = run(pl_in=pl)
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y, equal_nan=True), (seed, elim, S)
