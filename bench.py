@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the rank logic)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--warm-only", action="store_true",
+                    help="compile this run's generated kernels into the cache (plan-only contexts, no GPU call) and exit: "
+                         "the profiling scripts do this BEFORE rocprofv3, under which the library refuses to spawn hipcc")
     return ap.parse_args()
 
 
@@ -222,8 +225,27 @@ def ped_name(ped):
     return "ped%d" % ped.n
 
 
+def warm_only(a):
+    """Generate + compile (or find in the cache) every kernel a run with these arguments launches."""
+    import famseq_amd as fs
+
+    names = [a.workload] + (["ped5", "ped15"] if a.workload == "ped10" and not a.no_side_configs else [])
+    for name in names:
+        ctx = fs.Context(fs.make_model(fs.synthetic_pedigree(name), lc=a.lc), device=-1)
+        for kv in a.option:
+            k, v = kv.split("=")
+            ctx.set_option(k, int(v))
+        ctx.set_option("enum_impl", 1)
+        if ctx.plan()["elim_supported"]:
+            ctx.set_option("engine", fs.ENGINE_ELIM)
+        print("warm:", name, {k: v for k, v in ctx.plan().items() if k.endswith("code_object")})
+        ctx.close()
+
+
 def main():
     a = parse()
+    if a.warm_only:
+        return warm_only(a)
     import torch
     import torch.distributed as dist
 

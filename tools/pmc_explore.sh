@@ -7,6 +7,8 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+# the library refuses to spawn hipcc under a profiler: make sure this run's kernels are in the cache first
+python3 $R/bench.py --warm-only "$@" > $O/warm.log 2>&1 || { echo "warm-up failed"; cat $O/warm.log; exit 1; }
 cd /tmp
 i=0
 for c in \

@@ -9,6 +9,8 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+# the library refuses to spawn hipcc under a profiler: make sure this run's kernels are in the cache first
+python3 $R/bench.py --warm-only "$@" > $O/warm.log 2>&1 || { echo "warm-up failed"; cat $O/warm.log; exit 1; }
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/kt.log 2>&1
 echo "kernel-trace rc=$?"

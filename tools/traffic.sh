@@ -7,6 +7,8 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+# the library refuses to spawn hipcc under a profiler: make sure this run's kernels are in the cache first
+python3 $R/bench.py --warm-only --workload $WL > $O/warm.log 2>&1 || { echo "warm-up failed"; cat $O/warm.log; exit 1; }
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 170 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --workload $WL --no-cpu-baseline --no-side-configs --no-elim --sites 1000000 --steps 2 --warmup 1 > $O/pmc_$c.log 2>&1
@@ -14,3 +16,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python3 tools/pmc_summary.py $O | grep "FETCH\|WRITE"
+python3 tools/traffic_json.py $O $WL
