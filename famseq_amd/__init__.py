@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "famseq_transmission_tables", "famseq_model_init", "famseq_device_count", "famseq_create",
     "famseq_destroy", "famseq_last_error", "famseq_set_option", "famseq_plan_json",
     "famseq_bn_batch", "famseq_bn_batch_sharded", "famseq_bn_batch_device", "famseq_bn_batch_device_sharded",
-    "famseq_bn_call_batch",
+    "famseq_bn_call_batch", "famseq_alloc_pinned", "famseq_free_pinned",
     "famseq_call_genotypes",
 ]
 PL_MISSING = 0xFFFF
@@ -112,6 +112,10 @@ def lib():
     L.famseq_bn_call_batch.argtypes = [C.c_void_p, C.c_int64, dp, C.POINTER(C.c_uint16), bp, ip, C.c_int32, dp, dp,
                                        C.POINTER(C.c_int8), bp]
     L.famseq_bn_call_batch.restype = C.c_int
+    L.famseq_alloc_pinned.argtypes = [C.c_size_t]
+    L.famseq_alloc_pinned.restype = C.c_void_p
+    L.famseq_free_pinned.argtypes = [C.c_void_p]
+    L.famseq_free_pinned.restype = None
     L.famseq_call_genotypes.argtypes = [dp, C.c_int64, C.POINTER(C.c_int8)]
     L.famseq_call_genotypes.restype = None
     _lib = L

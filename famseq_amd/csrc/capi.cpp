@@ -800,6 +800,16 @@ extern "C" int famseq_bn_batch_device_sharded(famseq_ctx *const *ctxs, int n_ctx
   return 0;
 }
 
+extern "C" void *famseq_alloc_pinned(size_t bytes) {
+  void *p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+extern "C" void famseq_free_pinned(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 extern "C" int famseq_bn_call_batch(famseq_ctx *c, int64_t n_sites, const double *lk, const uint16_t *pl16,
                                     const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, double *gpp,
                                     double *fpp, int8_t *fgt, uint8_t *status) {

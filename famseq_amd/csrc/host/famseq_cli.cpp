@@ -25,11 +25,19 @@
 #include <fstream>
 #include <iostream>
 #include <charconv>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <string_view>
 #include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "famseq_hip.h"
 
@@ -578,6 +586,55 @@ struct PackWriter {
 // run is bounded by the host link and the disk, not by printing 6 n_seq numbers per site.
 const char kPoMagic[8] = {'F', 'S', 'P', 'O', '0', '0', '0', '1'};
 
+// One batch of the packed-PL driver.  The arrays the GPU call reads and writes live in pinned host
+// memory (famseq_alloc_pinned: both directions of the host link at their full rate).
+struct PlBatch {
+  size_t cap = 0, k = 0, n = 0;
+  uint8_t *flags = nullptr, *status = nullptr;
+  uint16_t *pl = nullptr;
+  double *gpp = nullptr, *fpp = nullptr;
+  int8_t *fgt = nullptr;
+  bool alloc(size_t cap_, size_t k_) {
+    cap = cap_;
+    k = k_;
+    flags = static_cast<uint8_t *>(famseq_alloc_pinned(cap));
+    status = static_cast<uint8_t *>(famseq_alloc_pinned(cap));
+    pl = static_cast<uint16_t *>(famseq_alloc_pinned(cap * k * 6));
+    gpp = static_cast<double *>(famseq_alloc_pinned(cap * k * 24));
+    fpp = static_cast<double *>(famseq_alloc_pinned(cap * k * 24));
+    fgt = static_cast<int8_t *>(famseq_alloc_pinned(cap * k));
+    return flags && status && pl && gpp && fpp && fgt;
+  }
+  void release() {
+    for (void *q : {(void *)flags, (void *)status, (void *)pl, (void *)gpp, (void *)fpp, (void *)fgt}) famseq_free_pinned(q);
+  }
+};
+
+// FIFO hand-off between the stages of the packed-PL pipeline (reader -> GPU -> writer -> reader).
+// -1 = the producer is done.
+class Channel {
+ public:
+  void put(int v) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      q_.push_back(v);
+    }
+    cv_.notify_one();
+  }
+  int take() {
+    std::unique_lock<std::mutex> g(mu_);
+    cv_.wait(g, [&] { return !q_.empty(); });
+    const int v = q_.front();
+    q_.pop_front();
+    return v;
+  }
+
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<int> q_;
+};
+
 bool run_pl(const Options &o, const Ped &ped) {
   std::ifstream fin(o.pl_file.c_str(), std::ios::binary);
   if (!fin.is_open()) {
@@ -688,64 +745,10 @@ bool run_pl(const Options &o, const Ped &ped) {
     fout << std::endl;
   }
 
-  const size_t cap = batch_capacity();
-  vector<char> raw(cap * rec);
-  vector<uint8_t> flags(cap), status(cap);
-  vector<uint16_t> pl(cap * k * 3);
-  vector<double> gpp(cap * k * 3), fpp(cap * k * 3);
-  vector<int8_t> fgt(cap * k);
-  bool ok = true;
-  while (ok) {
-    size_t n = 0;
-    if (o.unpack_mode) {  // the result file's blocks set the pace
-      uint64_t bn = 0;
-      fpo.read(reinterpret_cast<char *>(&bn), 8);
-      if (!fpo || bn == 0) break;
-      if (bn > cap) {
-        raw.resize(bn * rec); flags.resize(bn); status.resize(bn); pl.resize(bn * k * 3);
-        gpp.resize(bn * k * 3); fpp.resize(bn * k * 3); fgt.resize(bn * k);
-      }
-      n = (size_t)bn;
-      fin.read(raw.data(), (std::streamsize)(n * rec));
-      fpo.read(reinterpret_cast<char *>(status.data()), (std::streamsize)n);
-      fpo.read(reinterpret_cast<char *>(gpp.data()), (std::streamsize)(n * k * 24));
-      fpo.read(reinterpret_cast<char *>(fpp.data()), (std::streamsize)(n * k * 24));
-      fpo.read(reinterpret_cast<char *>(fgt.data()), (std::streamsize)(n * k));
-      if (!fpo || size_t(fin.gcount()) != n * rec) {
-        std::cout << "The packed files end early or do not belong together." << std::endl;
-        ok = false;
-        break;
-      }
-    } else {
-      fin.read(raw.data(), (std::streamsize)(cap * rec));
-      n = size_t(fin.gcount()) / rec;
-      if (n == 0) break;
-    }
-    parallel_for(n, [&](size_t s) {  // de-interleave: flags[] and the PED-matched columns of pl[]
-      const char *r = raw.data() + s * rec;
-      flags[s] = uint8_t(r[0]);
-      for (size_t j = 0; j < k; j++) std::memcpy(&pl[(s * k + j) * 3], r + 1 + 6 * seq_cols[j], 6);
-    });
-    if (!o.unpack_mode) {
-      const int rc = famseq_bn_call_batch(ctx, (int64_t)n, nullptr, pl.data(), flags.data(), seq_members.data(), (int32_t)k,
-                                          gpp.data(), fpp.data(), fgt.data(), status.data());
-      if (rc != 0) {
-        std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx) << std::endl;
-        ok = false;
-        break;
-      }
-    }
-    if (o.bin_output) {
-      const uint64_t bn = n;
-      fout.write(reinterpret_cast<const char *>(&bn), 8);
-      fout.write(reinterpret_cast<const char *>(status.data()), (std::streamsize)n);
-      fout.write(reinterpret_cast<const char *>(gpp.data()), (std::streamsize)(n * k * 24));
-      fout.write(reinterpret_cast<const char *>(fpp.data()), (std::streamsize)(n * k * 24));
-      fout.write(reinterpret_cast<const char *>(fgt.data()), (std::streamsize)(n * k));
-      written += n;
-      continue;
-    }
-    vector<string> lines(n);
+  // Text of one batch (what `FamSeq PL` prints per site), formatted on all cores.
+  auto format_lines = [&](size_t n, const uint16_t *pl, const uint8_t *status, const double *gpp, const double *fpp, const int8_t *fgt,
+                          vector<string> &lines) {
+    lines.resize(n);
     parallel_for(n, [&](size_t s) {
       string &line = lines[s];
       line.assign("PL:GPP:FPP:FGT\t");
@@ -772,14 +775,148 @@ bool run_pl(const Options &o, const Ped &ped) {
       }
       line += '\n';
     });
+  };
+
+  if (!o.unpack_mode) {
+    // `FamSeq PL`: read, GPU and write run concurrently — a reader thread de-interleaves batch b + 1 out
+    // of the memory-mapped file while the GPU call of batch b runs on this thread and a writer thread
+    // stores (or prints) batch b - 1.  Three batches of pinned buffers go round; order is kept by the
+    // FIFOs.  (The serial loop this replaces spent two thirds of its time with the GPU idle.)
+    const long header = (long)fin.tellg();
+    fin.close();
+    const int fd = ::open(o.pl_file.c_str(), O_RDONLY);
+    struct stat st;
+    if (fd < 0 || ::fstat(fd, &st) != 0) {
+      std::cout << "Cannot open " << o.pl_file << std::endl;
+      return false;
+    }
+    const size_t body = (size_t)st.st_size > (size_t)header ? (size_t)st.st_size - (size_t)header : 0;
+    const size_t total = body / rec;  // whole records only, like the stream reader
+    const char *map = nullptr;
+    if (total) {
+      void *mp = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (mp == MAP_FAILED) {
+        std::cout << "Cannot map " << o.pl_file << std::endl;
+        ::close(fd);
+        return false;
+      }
+      ::madvise(mp, (size_t)st.st_size, MADV_SEQUENTIAL);
+      map = static_cast<const char *>(mp);
+    }
+    const size_t cap = std::min(batch_capacity(), std::max<size_t>(total, 1));
+    constexpr int kBatches = 3;
+    PlBatch bt[kBatches];
+    bool ok = true;
+    for (PlBatch &b : bt) ok = b.alloc(cap, k) && ok;
+    if (!ok) std::cerr << "cannot allocate pinned host buffers" << std::endl;
+    Channel to_reader, to_gpu, to_writer;
+    for (int i = 0; i < kBatches; i++) to_reader.put(i);
+    std::thread reader([&] {
+      for (size_t at = 0; at < total && ok;) {
+        const int i = to_reader.take();
+        PlBatch &b = bt[i];
+        b.n = std::min(cap, total - at);
+        const char *raw = map + header + at * rec;
+        parallel_for(b.n, [&](size_t s) {  // de-interleave: flags[] and the PED-matched columns of pl[]
+          const char *r = raw + s * rec;
+          b.flags[s] = uint8_t(r[0]);
+          for (size_t j = 0; j < k; j++) std::memcpy(&b.pl[(s * k + j) * 3], r + 1 + 6 * seq_cols[j], 6);
+        });
+        at += b.n;
+        to_gpu.put(i);
+      }
+      to_gpu.put(-1);
+    });
+    bool write_ok = true;
+    std::thread writer([&] {
+      vector<string> lines;
+      for (;;) {
+        const int i = to_writer.take();
+        if (i < 0) break;
+        PlBatch &b = bt[i];
+        if (o.bin_output) {
+          const uint64_t bn = b.n;
+          fout.write(reinterpret_cast<const char *>(&bn), 8);
+          fout.write(reinterpret_cast<const char *>(b.status), (std::streamsize)b.n);
+          fout.write(reinterpret_cast<const char *>(b.gpp), (std::streamsize)(b.n * k * 24));
+          fout.write(reinterpret_cast<const char *>(b.fpp), (std::streamsize)(b.n * k * 24));
+          fout.write(reinterpret_cast<const char *>(b.fgt), (std::streamsize)(b.n * k));
+          written += b.n;
+        } else {
+          format_lines(b.n, b.pl, b.status, b.gpp, b.fpp, b.fgt, lines);
+          for (size_t s = 0; s < b.n; s++) fout.write(lines[s].data(), (std::streamsize)lines[s].size());
+        }
+        write_ok = write_ok && !fout.fail();
+        to_reader.put(i);
+      }
+    });
+    for (;;) {  // the GPU stage, on the thread that owns the context
+      const int i = to_gpu.take();
+      if (i < 0) break;
+      PlBatch &b = bt[i];
+      if (ok) {
+        const int rc = famseq_bn_call_batch(ctx, (int64_t)b.n, nullptr, b.pl, b.flags, seq_members.data(), (int32_t)k, b.gpp, b.fpp,
+                                            b.fgt, b.status);
+        if (rc != 0) {
+          std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx) << std::endl;
+          ok = false;
+        }
+      }
+      if (ok) to_writer.put(i);
+      else to_reader.put(i);  // keep the reader from waiting on a batch that will never be written
+    }
+    to_writer.put(-1);
+    reader.join();
+    writer.join();
+    for (PlBatch &b : bt) b.release();
+    if (map) ::munmap(const_cast<char *>(map), (size_t)st.st_size);
+    ::close(fd);
+    if (o.bin_output) {
+      fout.seekp(16);
+      fout.write(reinterpret_cast<const char *>(&written), 8);
+    }
+    fout.close();
+    famseq_destroy(ctx);
+    return ok && write_ok && !fout.fail();
+  }
+
+  // `FamSeq unpack`: the result file's blocks set the pace; no GPU, a plain loop
+  size_t cap = batch_capacity();
+  vector<char> raw(cap * rec);
+  vector<uint8_t> status(cap);
+  vector<uint16_t> pl(cap * k * 3);
+  vector<double> gpp(cap * k * 3), fpp(cap * k * 3);
+  vector<int8_t> fgt(cap * k);
+  vector<string> lines;
+  bool ok = true;
+  while (ok) {
+    uint64_t bn = 0;
+    fpo.read(reinterpret_cast<char *>(&bn), 8);
+    if (!fpo || bn == 0) break;
+    if (bn > cap) {
+      cap = (size_t)bn;
+      raw.resize(cap * rec); status.resize(cap); pl.resize(cap * k * 3);
+      gpp.resize(cap * k * 3); fpp.resize(cap * k * 3); fgt.resize(cap * k);
+    }
+    const size_t n = (size_t)bn;
+    fin.read(raw.data(), (std::streamsize)(n * rec));
+    fpo.read(reinterpret_cast<char *>(status.data()), (std::streamsize)n);
+    fpo.read(reinterpret_cast<char *>(gpp.data()), (std::streamsize)(n * k * 24));
+    fpo.read(reinterpret_cast<char *>(fpp.data()), (std::streamsize)(n * k * 24));
+    fpo.read(reinterpret_cast<char *>(fgt.data()), (std::streamsize)(n * k));
+    if (!fpo || size_t(fin.gcount()) != n * rec) {
+      std::cout << "The packed files end early or do not belong together." << std::endl;
+      ok = false;
+      break;
+    }
+    parallel_for(n, [&](size_t s) {  // the PED-matched columns of pl[]
+      const char *r = raw.data() + s * rec;
+      for (size_t j = 0; j < k; j++) std::memcpy(&pl[(s * k + j) * 3], r + 1 + 6 * seq_cols[j], 6);
+    });
+    format_lines(n, pl.data(), status.data(), gpp.data(), fpp.data(), fgt.data(), lines);
     for (size_t s = 0; s < n; s++) fout.write(lines[s].data(), (std::streamsize)lines[s].size());
   }
-  if (o.bin_output) {
-    fout.seekp(16);
-    fout.write(reinterpret_cast<const char *>(&written), 8);
-  }
   fout.close();
-  if (ctx) famseq_destroy(ctx);
   return ok && !fout.fail();
 }
 

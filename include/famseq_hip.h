@@ -185,6 +185,13 @@ int famseq_bn_call_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, con
                          const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, double *gpp, double *fpp,
                          int8_t *fgt, uint8_t *status);
 
+/* Page-locked host memory for the buffers handed to famseq_bn_batch / famseq_bn_call_batch: with pinned
+ * buffers both directions of the host link run at their full rate at once (the callers of the reference's
+ * operator own their buffers, file.cpp:565; this is how to own fast ones without linking HIP).  Returns NULL
+ * when there is no device or no memory; famseq_free_pinned(NULL) is a no-op. */
+void *famseq_alloc_pinned(size_t bytes);
+void famseq_free_pinned(void *p);
+
 /* get_postRlt (family.cpp:636-665) for one N x 3 posterior row block: arg-max with
  * strict '<' starting from -1, so ties resolve to the lowest genotype. */
 void famseq_call_genotypes(const double *post, int64_t n_rows, int8_t *geno);
