@@ -25,6 +25,7 @@
 #include <fstream>
 #include <iostream>
 #include <charconv>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -610,6 +611,33 @@ struct PlBatch {
   }
 };
 
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Write `bytes` at `off` of fd from `parts` threads (the copy into the page cache is the slow part of
+// storing 490 bytes per site; it parallelises, a single stream writer does not).
+bool pwrite_parallel(int fd, const void *data, size_t bytes, off_t off, int parts) {
+  if (bytes < (size_t(1) << 20)) parts = 1;
+  std::vector<std::thread> pool;
+  std::vector<char> good(parts, 1);
+  for (int t = 0; t < parts; ++t)
+    pool.emplace_back([&, t] {
+      size_t lo = bytes * t / parts, hi = bytes * (t + 1) / parts;
+      const char *p = static_cast<const char *>(data);
+      while (lo < hi) {
+        const ssize_t w = ::pwrite(fd, p + lo, hi - lo, off + (off_t)lo);
+        if (w <= 0) {
+          good[t] = 0;
+          return;
+        }
+        lo += (size_t)w;
+      }
+    });
+  for (std::thread &th : pool) th.join();
+  for (char g : good)
+    if (!g) return false;
+  return true;
+}
+
 // FIFO hand-off between the stages of the packed-PL pipeline (reader -> GPU -> writer -> reader).
 // -1 = the producer is done.
 class Channel {
@@ -809,11 +837,14 @@ bool run_pl(const Options &o, const Ped &ped) {
     bool ok = true;
     for (PlBatch &b : bt) ok = b.alloc(cap, k) && ok;
     if (!ok) std::cerr << "cannot allocate pinned host buffers" << std::endl;
+    double t_read = 0, t_gpu = 0, t_write = 0;
+    const double t_start = now_s();
     Channel to_reader, to_gpu, to_writer;
     for (int i = 0; i < kBatches; i++) to_reader.put(i);
     std::thread reader([&] {
       for (size_t at = 0; at < total && ok;) {
         const int i = to_reader.take();
+        const double t0 = now_s();
         PlBatch &b = bt[i];
         b.n = std::min(cap, total - at);
         const char *raw = map + header + at * rec;
@@ -823,30 +854,45 @@ bool run_pl(const Options &o, const Ped &ped) {
           for (size_t j = 0; j < k; j++) std::memcpy(&b.pl[(s * k + j) * 3], r + 1 + 6 * seq_cols[j], 6);
         });
         at += b.n;
+        t_read += now_s() - t0;
         to_gpu.put(i);
       }
       to_gpu.put(-1);
     });
     bool write_ok = true;
+    // packed results go out through pwrite on a descriptor of their own (positions are known: the
+    // header, then fixed-layout blocks), several threads per block
+    int ofd = -1;
+    off_t opos = 0;
+    if (o.bin_output) {
+      fout.flush();
+      opos = (off_t)fout.tellp();
+      ofd = ::open(o.out_file.c_str(), O_WRONLY);
+      if (ofd < 0) write_ok = false;
+    }
     std::thread writer([&] {
       vector<string> lines;
       for (;;) {
         const int i = to_writer.take();
         if (i < 0) break;
+        const double t0 = now_s();
         PlBatch &b = bt[i];
         if (o.bin_output) {
           const uint64_t bn = b.n;
-          fout.write(reinterpret_cast<const char *>(&bn), 8);
-          fout.write(reinterpret_cast<const char *>(b.status), (std::streamsize)b.n);
-          fout.write(reinterpret_cast<const char *>(b.gpp), (std::streamsize)(b.n * k * 24));
-          fout.write(reinterpret_cast<const char *>(b.fpp), (std::streamsize)(b.n * k * 24));
-          fout.write(reinterpret_cast<const char *>(b.fgt), (std::streamsize)(b.n * k));
+          const size_t wide = b.n * k * 24;
+          bool g = write_ok && ::pwrite(ofd, &bn, 8, opos) == 8 && pwrite_parallel(ofd, b.status, b.n, opos + 8, 1);
+          g = g && pwrite_parallel(ofd, b.gpp, wide, opos + 8 + (off_t)b.n, 4);
+          g = g && pwrite_parallel(ofd, b.fpp, wide, opos + 8 + (off_t)(b.n + wide), 4);
+          g = g && pwrite_parallel(ofd, b.fgt, b.n * k, opos + 8 + (off_t)(b.n + 2 * wide), 1);
+          opos += 8 + (off_t)(b.n + 2 * wide + b.n * k);
+          write_ok = g;
           written += b.n;
         } else {
           format_lines(b.n, b.pl, b.status, b.gpp, b.fpp, b.fgt, lines);
           for (size_t s = 0; s < b.n; s++) fout.write(lines[s].data(), (std::streamsize)lines[s].size());
+          write_ok = write_ok && !fout.fail();
         }
-        write_ok = write_ok && !fout.fail();
+        t_write += now_s() - t0;
         to_reader.put(i);
       }
     });
@@ -855,8 +901,10 @@ bool run_pl(const Options &o, const Ped &ped) {
       if (i < 0) break;
       PlBatch &b = bt[i];
       if (ok) {
+        const double t0 = now_s();
         const int rc = famseq_bn_call_batch(ctx, (int64_t)b.n, nullptr, b.pl, b.flags, seq_members.data(), (int32_t)k, b.gpp, b.fpp,
                                             b.fgt, b.status);
+        t_gpu += now_s() - t0;
         if (rc != 0) {
           std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx) << std::endl;
           ok = false;
@@ -872,10 +920,15 @@ bool run_pl(const Options &o, const Ped &ped) {
     if (map) ::munmap(const_cast<char *>(map), (size_t)st.st_size);
     ::close(fd);
     if (o.bin_output) {
-      fout.seekp(16);
-      fout.write(reinterpret_cast<const char *>(&written), 8);
+      if (ofd >= 0) {
+        write_ok = write_ok && ::pwrite(ofd, &written, 8, 16) == 8;
+        ::close(ofd);
+      }
     }
     fout.close();
+    if (std::getenv("FAMSEQ_TIMING"))
+      std::cerr << "FamSeq PL: " << total << " sites, pipeline " << now_s() - t_start << " s (busy: reader " << t_read << ", GPU calls "
+                << t_gpu << ", writer " << t_write << ")" << std::endl;
     famseq_destroy(ctx);
     return ok && write_ok && !fout.fail();
   }

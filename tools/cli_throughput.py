@@ -25,7 +25,7 @@ cli = os.path.join(ROOT, "bin", "FamSeq")
 def run(a, label):
     ts = []
     for _ in range(2):
-        t0 = time.time(); subprocess.check_call([cli] + a, stdout=subprocess.DEVNULL); ts.append(time.time() - t0)
+        t0 = time.time(); subprocess.check_call([cli] + a, stdout=subprocess.DEVNULL, env=dict(os.environ, FAMSEQ_TIMING="1")); ts.append(time.time() - t0)
     print("%-14s %.2f s  %.2f M sites/s   [first run %.2f s]" % (label, ts[1], n / ts[1] / 1e6, ts[0]), flush=True)
 
 
