@@ -165,6 +165,7 @@ class Gen {
   }
 
   std::string body() {
+    if (const char *e = std::getenv("FAMSEQ_LANE_PIN")) pin_style_ = std::atoi(e);  // tuning aid
     compute_deps();
     choose_superleaf();
     order_outer_loops();
@@ -549,6 +550,18 @@ class Gen {
     }
   }
 
+  // Where prefix products are formed the instruction order is pinned (left alone, hipcc forms the
+  // products of the whole unrolled tree ahead of their uses and spills).  pin_style_ 1: an empty asm
+  // statement tying the values to registers at that point; 2: a scheduling barrier
+  // (__builtin_amdgcn_sched_barrier: nothing is moved across, and no instruction is emitted — the asm
+  // form costs an s_nop each); 0: none.
+  int pin_style_ = 1;
+  std::string pin(const std::string &operands, const std::string &ind) const {
+    if (pin_style_ == 2) return ind + "__builtin_amdgcn_sched_barrier(0);\n";
+    if (pin_style_ == 0) return "";
+    return ind + "asm volatile(\"\" : " + operands + ");\n";
+  }
+
   void level(int k, const std::string &P, std::vector<int> &dig, const std::string &ind) {
     const int p = s_.unrolled[k];
     if (sl_ >= 2 && k == nu_ - sl_) {
@@ -569,9 +582,9 @@ class Gen {
       o_ << ind << "double " << pg << " = " << P << " * " << w_name(k, g, dig) << ";\n"
          << ind << "b" << p << "_" << g << " = __builtin_fma(" << pg << ", " << q_name(k + 1, dig) << ", b" << p << "_" << g
          << ");\n"
-         << ind << "asm volatile(\"\" : \"+v\"(" << pg << "), \"+v\"(b" << p << "_" << g << "));\n";
+         << pin("\"+v\"(" + pg + "), \"+v\"(b" + num(p) + "_" + num(g) + ")", ind);
       level(k + 1, pg, dig, ind);
-      o_ << ind << "asm volatile(\"\" : \"+v\"(" << P << "), \"+v\"(b" << p << "_" << g << "));\n";
+      o_ << pin("\"+v\"(" + P + "), \"+v\"(b" + num(p) + "_" + num(g) + ")", ind);
     }
   }
 

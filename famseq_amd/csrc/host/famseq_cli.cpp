@@ -744,8 +744,10 @@ bool run_pl(const Options &o, const Ped &ped) {
     }
     if (o.gN.size() == 3) std::copy(o.gN.begin(), o.gN.end(), m.genoProbN);
   } else {
+    const double t0 = now_s();
     ctx = make_ctx(o, ped, sequenced, m);
     if (!ctx) return false;
+    if (std::getenv("FAMSEQ_TIMING")) std::cerr << "FamSeq PL: context (HIP start-up, plan, kernels) " << now_s() - t0 << " s" << std::endl;
   }
   std::ofstream fout(o.out_file.c_str(), o.bin_output ? std::ios::binary : std::ios::out);
   uint64_t written = 0;
@@ -835,7 +837,9 @@ bool run_pl(const Options &o, const Ped &ped) {
     constexpr int kBatches = 3;
     PlBatch bt[kBatches];
     bool ok = true;
+    const double t_alloc0 = now_s();
     for (PlBatch &b : bt) ok = b.alloc(cap, k) && ok;
+    const double t_alloc = now_s() - t_alloc0;
     if (!ok) std::cerr << "cannot allocate pinned host buffers" << std::endl;
     double t_read = 0, t_gpu = 0, t_write = 0;
     const double t_start = now_s();
@@ -928,7 +932,7 @@ bool run_pl(const Options &o, const Ped &ped) {
     fout.close();
     if (std::getenv("FAMSEQ_TIMING"))
       std::cerr << "FamSeq PL: " << total << " sites, pipeline " << now_s() - t_start << " s (busy: reader " << t_read << ", GPU calls "
-                << t_gpu << ", writer " << t_write << ")" << std::endl;
+                << t_gpu << ", writer " << t_write << "); pinned buffers " << t_alloc << " s" << std::endl;
     famseq_destroy(ctx);
     return ok && write_ok && !fout.fail();
   }
@@ -1403,6 +1407,8 @@ int main(int argc, char **argv) {
     std::cout << "Cannot read Ped file: " << o.ped_file << "." << std::endl << "Cannot set family." << std::endl;
     return -1;
   }
+  const double t0 = now_s();
   const bool ok = o.pl_mode ? run_pl(o, ped) : (o.lk_mode ? run_lk(o, ped) : run_vcf(o, ped));
+  if (std::getenv("FAMSEQ_TIMING")) std::cerr << "FamSeq " << mode << ": " << now_s() - t0 << " s in the driver" << std::endl;
   return ok ? 0 : -1;
 }
