@@ -105,7 +105,7 @@ int read_res(const std::string &obj) {
 
 }  // namespace
 
-std::string jit_compile(const std::string &source, int *scratch_bytes) {
+std::string jit_compile(const std::string &source, int *scratch_bytes, bool note_suffices) {
   // One compilation at a time per process: famseq_bn_batch*_sharded runs a host thread per ctx, and
   // with a cold cache every one of them arrives here with the same source.  The first compiles,
   // the others find the object.  (Scratch names are unique per call as well, so that processes
@@ -127,6 +127,15 @@ std::string jit_compile(const std::string &source, int *scratch_bytes) {
   if (exists(obj)) {
     if (scratch_bytes) *scratch_bytes = read_res(obj);
     return obj;
+  }
+  if (note_suffices && scratch_bytes) {  // a variant that was tried before and lost: its note answers the question
+    for (const std::string &o : {std::getenv("FAMSEQ_KERNEL_CACHE") ? obj : shipped, obj}) {  // (an explicit cache: that directory only)
+      const int v = read_res(o);
+      if (v >= 0) {
+        *scratch_bytes = v;
+        return "";
+      }
+    }
   }
   if (const char *why = profiler_env())
     throw std::runtime_error(std::string("kernel ") + name + " is not in the cache (" + dir + ") and a profiler is attached ($" +
@@ -187,18 +196,28 @@ std::string jit_pick_variant(const std::function<std::string(int)> &generate, in
   int best_scratch = -1, best_i = 0;
   int first = 0;
   if (const char *e = std::getenv("FAMSEQ_VARIANT_MIN")) first = std::max(0, std::min(std::atoi(e), n_variants - 1));  // tuning aid
+  std::vector<std::string> rejected;  // code objects of variants that lost: only their resource notes are kept
+  std::string best_obj;
   for (int v = first; v < n_variants; ++v) {
     std::string src = generate(v);
     int scratch = -1;
-    (void)jit_compile(src, &scratch);
+    const std::string obj = jit_compile(src, &scratch, /*note_suffices=*/true);
     if (scratch < 0) scratch = 0;  // an object without a note (older cache): take it as it is
     if (best.empty() || scratch < best_scratch) {
+      if (!best_obj.empty()) rejected.push_back(best_obj);
       best.swap(src);
+      best_obj = obj;
       best_scratch = scratch;
       best_i = v;
+    } else if (!obj.empty()) {
+      rejected.push_back(obj);
     }
     if (best_scratch <= kSpillTolerance) break;
   }
+  // a cache directory holds one code object per kernel, not one per variant tried (the notes are tiny and
+  // spare the next process the compilations); shipped (read-only) directories are left alone
+  for (const std::string &o : rejected)
+    if (!o.empty() && o != best_obj) (void)::unlink(o.c_str());
   if (picked) *picked = best_i;
   return best;
 }

@@ -27,7 +27,9 @@ JitKernel jit_load(const std::string &source, const std::string &entry);
 // Compile into the cache without loading (no GPU needed); returns the code-object path.
 // *scratch_bytes (optional) receives the kernel's scratch (register spill) bytes per lane as
 // hipcc reported them, kept in <hash>.res next to the object; -1 when unknown.
-std::string jit_compile(const std::string &source, int *scratch_bytes = nullptr);
+// note_suffices: when the object is not there but its resource note is (a variant that lost an earlier
+// jit_pick_variant), return "" with *scratch_bytes set instead of compiling again.
+std::string jit_compile(const std::string &source, int *scratch_bytes = nullptr, bool note_suffices = false);
 // The generators can trade instruction-level parallelism against register pressure
 // (`variant` 0 = most parallel).  Compiles variants in order and returns the source of the
 // first one that does not spill (more than 16 bytes per lane), or of the one that spills least.  *picked = its index.

@@ -78,6 +78,7 @@ extern "C" void famseq_enum_lane(const double *lk, const unsigned char *fl, doub
 
 
 def host_source(src: str, threads=False) -> str:
+    src = src.replace("__builtin_amdgcn_sched_barrier(0);", "")  # scheduling pins: no code on the device either
     if threads:
         src = src.replace("#include <hip/hip_runtime.h>", SHIM_THREADS)
         src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() pthread_barrier_wait(&wg_barrier_)", src)
@@ -415,7 +416,7 @@ def _threaded_call_kernel(model, elim, bt, cache, monkeypatch):
     reads_rows = "lg[" in src
     shim = SHIM_THREADS.replace("#define famseq_enum_lane famseq_enum_lane_one_thread", "#define %s kernel_one_thread_" % entry)
     shim += SHIM_CALL + "#define __builtin_amdgcn_ballot_w64(p) ((unsigned long)(p))\n"
-    src = src.replace("#include <hip/hip_runtime.h>", shim)
+    src = src.replace("#include <hip/hip_runtime.h>", shim).replace("__builtin_amdgcn_sched_barrier(0);", "")
     src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() pthread_barrier_wait(&wg_barrier_)", src)
     src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "").replace("__attribute__((address_space(3)))", "")
     src = re.sub(r'asm volatile\(""[^\n;]*\);', "", src.replace('extern "C" __global__', "static"))
