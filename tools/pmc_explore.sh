@@ -24,3 +24,4 @@ for c in \
 done
 cd $R
 python3 tools/pmc_summary.py $O
+rm -rf $O/pmc_*/

@@ -26,3 +26,18 @@ cd $R
 python3 tools/pmc_summary.py $O
 cp $O/kt/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 head -3 $O/kernel_stats.csv | cut -c1-220
+# per-launch durations of our kernels (told apart by LDS size), then drop the raw traces: gpurun brings back 64 MiB at most
+python3 - "$O" <<'PY'
+import collections, csv, glob, json, sys
+o = sys.argv[1]
+per = collections.defaultdict(list)
+for f in glob.glob(o + "/kt/*/*_kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "famseq_" in r["Kernel_Name"] or "bn_enum" in r["Kernel_Name"]:
+            per["%s[lds=%s]" % (r["Kernel_Name"].split("(")[0][:24], r["LDS_Block_Size"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+out = {k: {"launches": len(v), "ms": [round(x, 4) for x in v[:12]], "mean_ms_excluding_first": sum(v[1:]) / max(1, len(v) - 1)} for k, v in per.items()}
+json.dump({"per_launch": out}, open(o + "/kernel_trace_durations.json", "w"), indent=1)
+for k, v in out.items():
+    print(k, v["launches"], "launches, mean %.4f ms" % v["mean_ms_excluding_first"])
+PY
+rm -rf $O/kt $O/pmc_*/

@@ -17,3 +17,4 @@ done
 cd $R
 python3 tools/pmc_summary.py $O | grep "FETCH\|WRITE"
 python3 tools/traffic_json.py $O $WL
+rm -rf $O/pmc_*/

@@ -40,6 +40,9 @@ out = {
     "round": rnd,
 }
 out["ratio_to_algorithmic"] = out["bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
-path = os.path.join(ROOT, "profiles", "hbm_traffic_%s%s.json" % (workload, "_elim" if elim else ""))
+# next to the counter summary (what gpurun brings back) and, when run in the repository itself, in profiles/
+name = "hbm_traffic_%s%s.json" % (workload, "_elim" if elim else "")
+json.dump(out, open(os.path.join(d, name), "w"), indent=1)
+path = os.path.join(ROOT, "profiles", name)
 json.dump(out, open(path, "w"), indent=1)
 print(path, json.dumps(out))
