@@ -198,6 +198,21 @@ def side_config(fs, torch, dev, stream, workload, steps, warmup, sites=0):
             "fp64_valu_frac": S * 3 ** n / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS}
 
 
+class quiet_stdout:
+    """Send whatever is written to file descriptor 1 to stderr for a while: RCCL prints its version banner
+    and gloo its connection messages on stdout from C++, and stdout is for the ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def self_launch(a):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children of this
     process (which has not initialised the GPU and never will), one per GPU, and pass their exit code
@@ -274,8 +289,9 @@ def main():
             # collective).  If it cannot come up on this node, the same two calls go over gloo rather
             # than losing the run: every rank sees the same environment, so all of them take this turn.
             try:
-                dist.init_process_group("nccl", device_id=dev)
-                dist.barrier()
+                with quiet_stdout():
+                    dist.init_process_group("nccl", device_id=dev)
+                    dist.barrier()
             except Exception as e:  # noqa: BLE001
                 print("bench.py: RCCL unavailable (%s); barrier/timing reduction over gloo" % str(e).splitlines()[0],
                       file=sys.stderr)
@@ -285,9 +301,13 @@ def main():
                     pass
                 os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
                 a.backend, red_dev = "gloo", torch.device("cpu")
-                dist.init_process_group("gloo")
+                with quiet_stdout():
+                    dist.init_process_group("gloo")
+                    dist.barrier()
         else:
-            dist.init_process_group("gloo")
+            with quiet_stdout():
+                dist.init_process_group("gloo")
+                dist.barrier()
 
     cfg, default_sites = WORKLOADS[a.workload]
     S = a.sites or default_sites
