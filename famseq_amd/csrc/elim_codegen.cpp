@@ -498,6 +498,10 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
   int early_max_n = 0;
   if (const char *e = std::getenv("FAMSEQ_PREFETCH_EARLY_MAXN")) early_max_n = std::atoi(e);  // tuning aid
   const bool early = prefetch && N <= early_max_n;
+  // How chunks are dealt to workgroups: contiguous ranges (default), or — FAMSEQ_CHUNK_STRIDE=1, an
+  // experiment — round robin, so that at any moment the grid reads one contiguous window of each array
+  bool strided = false;
+  if (const char *e = std::getenv("FAMSEQ_CHUNK_STRIDE")) strided = std::atoi(e) != 0;  // tuning aid
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
@@ -549,7 +553,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  if (!whole) { TAIL(g_[e] = s_io[a]) } \\\n"
     << "  else if (v16) { WALK16(v2d v_; v_.x = s_io[a]; v_.y = s_io[a1]; __builtin_nontemporal_store(v_, (v2d *)(g_ + e))) } \\\n"
     << "  else { WALK8(__builtin_nontemporal_store(s_io[a], g_ + e)) } }\n"
-    << "#define PREFETCH(G) { const double *g_ = (G) + (site0 + BT) * W3; \\\n"
+    << "#define PREFETCH(G) { const double *g_ = (G) + (site0 + " << (strided ? "(long)gridDim.x * BT" : "BT") << ") * W3; \\\n"
     << "  if (v16) { WALK16(pre[k] = *(const v2d *)(g_ + e); (void)a1) } \\\n"
     << "  else { WALK8(((double *)pre)[k] = g_[e]) } }\n"
     << "#define STAGE_PRE() { \\\n"
@@ -571,8 +575,9 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  const int tid = threadIdx.x;\n"
     << "  for (int i = tid; i < 432; i += BT) s_tc[i] = tc_g[i];\n"
     << "  const long chunks = (n_sites + BT - 1) / BT;\n"
-    << "  const long per_wg = (chunks + gridDim.x - 1) / gridDim.x;\n"
-    << "  const long c_lo = (long)blockIdx.x * per_wg, c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;\n"
+    << (strided ? "  const long c_lo = blockIdx.x, c_hi = chunks;\n"
+                : "  const long per_wg = (chunks + gridDim.x - 1) / gridDim.x;\n"
+                  "  const long c_lo = (long)blockIdx.x * per_wg, c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;\n")
     << "  const double kNaN = __builtin_nan(\"\");\n"
     << "  double *row = s_io + tid * ROW;\n"
     // (regs_l = false) volatile forces a fresh LDS read per use.  The address space is spelled out:
@@ -587,7 +592,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
                     "  __shared__ signed char s_fgt[BT * NMEM];  // arg-max genotype of every member of every site of the chunk\n"
                     "  for (int i = tid; i < NMEM; i += BT) { s_col[i] = call_g->col[i]; s_seq[i] = i < call_g->n_seq ? call_g->seq[i] : 0; }\n"
                   : "")
-    << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
+    << (strided ? "  for (long ch = c_lo; ch < c_hi; ch += gridDim.x) {\n" : "  for (long ch = c_lo; ch < c_hi; ++ch) {\n")
     << "    const long site0 = ch * BT;\n"
     << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
     << "    const int nel = ns * W3;\n"
@@ -597,7 +602,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     // the next chunk's rows were requested during the previous chunk's output phases
     s << "    if (have_pre) { STAGE_PRE(); } else { STAGE_IN(lk_g); }\n";
     if (early)
-      s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
+      s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
   } else {
     s << (call_mode ? "    STAGE_IN_ANY();\n" : "    STAGE_IN(lk_g);\n");
@@ -625,7 +630,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       << (call_mode ? "      ROW_TO_CALL();  // the BN posterior as printed (FPP) and the genotype call\n" : "")
       << "    }\n";
     if (prefetch && !early)
-      s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
+      s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
     s
       << "    LDS_BARRIER();\n"
@@ -657,7 +662,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     if (prefetch && !early)
       // software prefetch: issue the next chunk's loads now; they stay in flight while this
       // chunk's two output phases run (the barriers below do not wait for vmcnt)
-      s << "    have_pre = ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are prefetched\n"
+      s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
       << "    if (have_pre) { PREFETCH(lk_g); }\n";
     single_pass(false, true);  // now the single posterior may take the row over
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
