@@ -155,6 +155,24 @@ def cpu_baseline(ped, cfg, seconds, n):
             "one_core_sites_per_s": n1 / t1, "configs_per_s_per_core": n1 / t1 * 3 ** n}
 
 
+def stream_probe_GBps(fs, torch, ctx, lk, post, single, stream, reps=10):
+    """What THIS device gives the kernels' traffic shape today: a bare elementwise kernel that reads one fp64
+    array and writes two of the same size (famseq_stream_probe), timed with HIP events on the launch stream.
+    MI355X devices differ by 10-20 % in this figure; the kernels are quoted against it next to the nominal peak.
+    (It overwrites post / single: call it after they have been checked.)"""
+    n = lk.numel()
+    for _ in range(3):
+        fs.stream_probe(ctx, n, lk.data_ptr(), post.data_ptr(), single.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(reps):
+        fs.stream_probe(ctx, n, lk.data_ptr(), post.data_ptr(), single.data_ptr(), stream.cuda_stream)
+    b.record(stream)
+    torch.cuda.synchronize()
+    return 3 * n * 8 / (a.elapsed_time(b) / reps * 1e-3) / 1e9
+
+
 def side_config(fs, torch, dev, stream, workload, steps, warmup, sites=0):
     """A second BASELINE configuration measured in the same process (same contract: resident
     inputs, HIP events on the launch stream), reported as a sub-object of the headline line."""
@@ -187,6 +205,7 @@ def side_config(fs, torch, dev, stream, workload, steps, warmup, sites=0):
     ok = int((status != 0).sum().item()) == 0 and float((post.sum(dim=2) - 1).abs().max().item()) < 1e-9
     bps = 72 * n + 2
     plan = ctx.plan()
+    probe = stream_probe_GBps(fs, torch, ctx, lk, post, single, stream)
     ctx.close()
     return {"workload": "BASELINE.json %s: %s, %d seeded synthetic sites, %d-member pedigree (3^%d = %d configs/site)"
                         % (CONFIG_OF[workload], workload, S, n, n, 3 ** n),
@@ -194,6 +213,7 @@ def side_config(fs, torch, dev, stream, workload, steps, warmup, sites=0):
             "ms_per_step": elapsed / steps * 1e3, "outputs_valid": ok,
             "roofline": {"bound": "hbm", "achieved": S * bps / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": S * bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": k_ms, "bytes_per_site": bps,
+                         "stream_probe_GBps": probe, "frac_of_stream_probe": S * bps / (k_ms * 1e-3) / 1e9 / probe,
                          "kernel": "famseq_enum_lane" if plan["enum_lane_code_object"] else "bn_enum_kernel<%d>" % plan["L"]},
             "fp64_valu_frac": S * 3 ** n / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS}
 
@@ -400,7 +420,15 @@ def main():
                          "read_frac": S * (24 * n + 1) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
         ctx.set_option("engine", fs.ENGINE_ENUM)
         del ref_post
+        # the same traffic as a bare elementwise kernel on this device, in this run (overwrites post / single,
+        # which have been checked and compared by now)
+        probe = stream_probe_GBps(fs, torch, ctx, lk, post, single, stream)
+        elim_out["roofline"]["stream_probe_GBps"] = probe
+        elim_out["roofline"]["frac_of_stream_probe"] = elim_out["roofline"]["achieved"] / probe
+        elim_out["roofline"]["stream_probe_note"] = ("bare elementwise kernel reading one fp64 array and writing two (famseq_stream_probe), "
+                                                     "same arrays, same run: what this device sustains for this traffic shape")
 
+    probe_GBps = elim_out["roofline"]["stream_probe_GBps"] if elim_out else stream_probe_GBps(fs, torch, ctx, lk, post, single, stream)
     if rank == 0:
         total_sites = job_sites
         value = total_sites * a.steps / elapsed
@@ -450,6 +478,7 @@ def main():
                          "bytes_per_site": bytes_per_site,
                          "read_GBps": S * (24 * n + 1) / (kernel_ms * 1e-3) / 1e9,
                          "frac_of_measured_copy_6290GBps": achieved / 6290.0,
+                         "stream_probe_GBps": probe_GBps, "frac_of_stream_probe": achieved / probe_GBps,
                          "note": ("a 3^N enumeration is bound by the fp64 vector ALU for N >= 7 (arithmetic intensity 3^N/24 "
                                   "flop/B): see fp64_valu; the same marginals by sum-product are HBM-bound: see elim_engine")
                          if n >= 7 and a.engine == "enum" else None},

@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "famseq_transmission_tables", "famseq_model_init", "famseq_device_count", "famseq_create",
     "famseq_destroy", "famseq_last_error", "famseq_set_option", "famseq_plan_json",
     "famseq_bn_batch", "famseq_bn_batch_sharded", "famseq_bn_batch_device", "famseq_bn_batch_device_sharded",
-    "famseq_bn_call_batch", "famseq_alloc_pinned", "famseq_free_pinned",
+    "famseq_bn_call_batch", "famseq_alloc_pinned", "famseq_free_pinned", "famseq_stream_probe",
     "famseq_call_genotypes",
 ]
 PL_MISSING = 0xFFFF
@@ -112,6 +112,8 @@ def lib():
     L.famseq_bn_call_batch.argtypes = [C.c_void_p, C.c_int64, dp, C.POINTER(C.c_uint16), bp, ip, C.c_int32, dp, dp,
                                        C.POINTER(C.c_int8), bp]
     L.famseq_bn_call_batch.restype = C.c_int
+    L.famseq_stream_probe.argtypes = [C.c_void_p, C.c_int64, vp, vp, vp, vp]
+    L.famseq_stream_probe.restype = C.c_int
     L.famseq_alloc_pinned.argtypes = [C.c_size_t]
     L.famseq_alloc_pinned.restype = C.c_void_p
     L.famseq_free_pinned.argtypes = [C.c_void_p]
@@ -235,6 +237,11 @@ class Context:
         rc = lib().famseq_bn_batch_device(self._h, int(n_sites), d_lk, d_flags or None, d_post, d_single or None,
                                           d_status or None, stream or None)
         self._check(rc, "famseq_bn_batch_device")
+
+
+def stream_probe(ctx, n_doubles, d_in, d_out1, d_out2, stream=0):
+    """famseq_stream_probe: the kernels' traffic shape as a bare elementwise kernel (diagnostic)."""
+    ctx._check(lib().famseq_stream_probe(ctx._h, int(n_doubles), d_in, d_out1, d_out2, stream or None), "famseq_stream_probe")
 
 
 def bn_batch_sharded(contexts, lk, flags=None):

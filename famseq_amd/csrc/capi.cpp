@@ -800,6 +800,17 @@ extern "C" int famseq_bn_batch_device_sharded(famseq_ctx *const *ctxs, int n_ctx
   return 0;
 }
 
+extern "C" int famseq_stream_probe(famseq_ctx *c, int64_t n_doubles, const double *d_in, double *d_out1, double *d_out2,
+                                   void *stream) {
+  if (!c) return FAMSEQ_E_ARG;
+  if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
+  if (n_doubles < 0 || (n_doubles > 0 && (!d_in || !d_out1 || !d_out2)) || ((uintptr_t)d_in | (uintptr_t)d_out1 | (uintptr_t)d_out2) & 15)
+    return fail(c, FAMSEQ_E_ARG, "bad probe arguments (arrays must be 16-byte aligned)");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, launch_stream_probe(d_in, d_out1, d_out2, n_doubles, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
 extern "C" void *famseq_alloc_pinned(size_t bytes) {
   void *p = nullptr;
   if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;

@@ -101,6 +101,21 @@ __global__ __launch_bounds__(256) void phred_call_kernel(const double *__restric
   }
 }
 
+// Diagnostic: the posterior kernels' traffic shape (read one fp64 array, write two of the same size) as a
+// bare elementwise kernel, 16 B per lane, non-temporal stores — what this device gives that shape today.
+// Devices of this kind differ by 10-20 % in what their memory system sustains (0.74 of the 8 TB/s nominal
+// peak on one box, 0.63 on another, same binary: tools/io_ceiling.hip); bench.py quotes the kernels against
+// this figure, measured in the same run, next to the nominal peak.
+typedef double v2d_ __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void stream_probe_kernel(const v2d_ *__restrict__ in, v2d_ *__restrict__ o1,
+                                                           v2d_ *__restrict__ o2, size_t n2) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+    const v2d_ v = in[i];
+    __builtin_nontemporal_store(v * 0.5, o1 + i);
+    __builtin_nontemporal_store(v * 2.0, o2 + i);
+  }
+}
+
 int grid_for(long n_sites) {
   const long tiles = (n_sites + kTileSites - 1) / kTileSites;
   return (int)(tiles < 1 ? 1 : (tiles > 16384 ? 16384 : tiles));
@@ -114,6 +129,13 @@ hipError_t launch_unpack_pl16(const uint16_t *d_pl, const int32_t *d_col_of_memb
   if (n_members < 1 || n_members > 20) return hipErrorInvalidValue;  // div_small's range
   hipLaunchKernelGGL(unpack_pl16_kernel, dim3(grid_for(n_sites)), dim3(256), 0, stream, d_pl,
                      d_col_of_member, d_lut, n_members, n_seq, (long)n_sites, d_lk);
+  return hipGetLastError();
+}
+
+hipError_t launch_stream_probe(const double *d_in, double *d_out1, double *d_out2, int64_t n_doubles, hipStream_t stream) {
+  if (n_doubles < 2) return hipSuccess;
+  hipLaunchKernelGGL(stream_probe_kernel, dim3(8192), dim3(256), 0, stream, reinterpret_cast<const v2d_ *>(d_in),
+                     reinterpret_cast<v2d_ *>(d_out1), reinterpret_cast<v2d_ *>(d_out2), (size_t)(n_doubles / 2));
   return hipGetLastError();
 }
 

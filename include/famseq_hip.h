@@ -185,6 +185,12 @@ int famseq_bn_call_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, con
                          const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, double *gpp, double *fpp,
                          int8_t *fgt, uint8_t *status);
 
+/* Diagnostic for measurement (bench.py): runs the posterior kernels' traffic shape — read one fp64 array of
+ * n_doubles, write two — as a bare elementwise kernel on `stream` and returns without synchronising.  What a
+ * device's memory system sustains for that shape differs between MI355X devices by 10-20 %; timing this next to
+ * the kernels says how much of what is attainable THERE they reach.  Arrays must be 16-byte aligned. */
+int famseq_stream_probe(famseq_ctx *ctx, int64_t n_doubles, const double *d_in, double *d_out1, double *d_out2, void *stream);
+
 /* Page-locked host memory for the buffers handed to famseq_bn_batch / famseq_bn_call_batch: with pinned
  * buffers both directions of the host link run at their full rate at once (the callers of the reference's
  * operator own their buffers, file.cpp:565; this is how to own fast ones without linking HIP).  Returns NULL
