@@ -506,6 +506,7 @@ def main():
             # the same kernel on 8 M sites (2.9 GB per step) is the pure HBM-streaming figure
             big = side_config(fs, torch, dev, stream, "ped5", max(a.steps, 20), max(a.warmup, 5), sites=8_000_000)
             out["configs_1_ped5"]["roofline"]["streaming_frac"] = big["roofline"]["frac"]
+            out["configs_1_ped5"]["roofline"]["streaming_frac_of_stream_probe"] = big["roofline"]["frac_of_stream_probe"]
             out["configs_1_ped5"]["roofline"]["streaming_note"] = "same kernel, 8 M sites: inputs no longer fit the Infinity Cache"
             # BASELINE configs[4] at its full size on this one GPU (0.5 s per launch: two timed steps)
             out["configs_4_ped15"] = side_config(fs, torch, dev, stream, "ped15", 2, 1)
