@@ -396,16 +396,22 @@ const std::string kCallHelpers = std::string(R"(
 #define FS_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
 #define FS_UMULHI(a, b) __umulhi(a, b)
 #endif
+// Pointers that reach the kernel through the argument struct are generic to the compiler, and every access
+// through them would be a flat_* instruction (counted on both vmcnt and lgkmcnt, waited for with both at 0).
+// They are global memory: say so.
+#ifndef FS_GLOBAL
+#define FS_GLOBAL __attribute__((address_space(1)))
+#endif
 )") + FS_PHRED_TEXT_ + std::string(R"(
 // The call path's arguments sit in one small struct in device memory behind a pointer that is null on the
 // plain path: its fields are fetched (scalar loads) only inside the stages that use them.  As ten more
 // kernel arguments they stayed live in SGPRs for the whole kernel and pushed the arithmetic into scratch.
 struct fs_call_args {
-  const unsigned short *pl;  // [n_sites][n_seq][3] packed PLs, or null: fp64 likelihood rows come in as usual
-  const double *lut;         // pow(10, -k / 10), k < 4096
-  const int *col, *seq;      // member -> VCF column or -1; VCF column -> member
-  double *gpp, *fpp;         // [n_sites][n_seq][3], either may be null
-  signed char *fgt;          // [n_sites][n_seq] or null
+  const FS_GLOBAL unsigned short *pl;  // [n_sites][n_seq][3] packed PLs, or null: fp64 likelihood rows come in as usual
+  const FS_GLOBAL double *lut;         // pow(10, -k / 10), k < 4096
+  const FS_GLOBAL int *col, *seq;      // member -> VCF column or -1; VCF column -> member
+  FS_GLOBAL double *gpp, *fpp;         // [n_sites][n_seq][3], either may be null
+  FS_GLOBAL signed char *fgt;          // [n_sites][n_seq] or null
   int n_seq;
   unsigned magic_w, magic_n;  // 2^32 / (3 n_seq) + 1, 2^32 / n_seq + 1: e / d = umulhi(e, magic) for e < 2^16; magic_n = 0 when n_seq = 1
 };
@@ -414,12 +420,12 @@ struct fs_call_args {
 // depend on the PLs, so that is two memory latencies per chunk instead of two per member.
 #define PL_ITEM(it_) { const int s_ = (it_) / NMEM, i_ = (it_) - s_ * NMEM, c_ = s_col[i_]; \
     double v0_ = 1.0, v1_ = 1.0, v2_ = 1.0; \
-    if (c_ >= 0) { const unsigned short *q_ = p_ + (s_ * n_seq + c_) * 3; const unsigned a_ = q_[0], b_ = q_[1], d_ = q_[2]; \
+    if (c_ >= 0) { const FS_GLOBAL unsigned short *q_ = p_ + (s_ * n_seq + c_) * 3; const unsigned a_ = q_[0], b_ = q_[1], d_ = q_[2]; \
       if (!(a_ == 0xFFFFu && b_ == 0xFFFFu && d_ == 0xFFFFu)) { \
         v0_ = a_ < 4096u ? lut_[a_] : 0.0; v1_ = b_ < 4096u ? lut_[b_] : 0.0; v2_ = d_ < 4096u ? lut_[d_] : 0.0; } } \
     double *w_ = s_io + s_ * ROW + 3 * i_; w_[0] = v0_; w_[1] = v1_; w_[2] = v2_; }
-#define STAGE_IN_PL() { const int n_seq = call_g->n_seq; const double *lut_ = call_g->lut; \
-  const unsigned short *p_ = call_g->pl + site0 * n_seq * 3; \
+#define STAGE_IN_PL() { const int n_seq = call_g->n_seq; const FS_GLOBAL double *lut_ = call_g->lut; \
+  const FS_GLOBAL unsigned short *p_ = call_g->pl + site0 * n_seq * 3; \
   if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) PL_ITEM(tid + j_ * BT) } \
   else { for (int it_ = tid; it_ < ns * NMEM; it_ += BT) PL_ITEM(it_) } }
 // The next chunk's packed PLs, fetched ahead in two steps that each sit behind a block of arithmetic (the
@@ -427,11 +433,11 @@ struct fs_call_args {
 // turns them into table look-ups whose values wait in registers (prel) until the next chunk's STAGE_PRE_PL
 // writes them into the rows.  Branch-free (clamped indices, selects afterwards): all of a lane's loads are in
 // flight together.  Without this the call path spent 47 % of its wave cycles in s_waitcnt (SQ_WAIT_ANY).
-#define PL_PREFETCH_A() { const int n_seq = call_g->n_seq; const unsigned short *p_ = call_g->pl + (site0 + BT) * n_seq * 3; \
+#define PL_PREFETCH_A() { const int n_seq = call_g->n_seq; const FS_GLOBAL unsigned short *p_ = call_g->pl + (site0 + BT) * n_seq * 3; \
   _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) { const int it_ = tid + j_ * BT, s_ = it_ / NMEM, i_ = it_ - s_ * NMEM, c_ = s_col[i_]; \
-    const unsigned short *q_ = p_ + (s_ * n_seq + (c_ >= 0 ? c_ : 0)) * 3; const unsigned a_ = q_[0], b_ = q_[1], d_ = q_[2]; \
+    const FS_GLOBAL unsigned short *q_ = p_ + (s_ * n_seq + (c_ >= 0 ? c_ : 0)) * 3; const unsigned a_ = q_[0], b_ = q_[1], d_ = q_[2]; \
     ppl[j_] = c_ >= 0 ? (a_ | (b_ << 16)) : 0xFFFFFFFFu; ppl2[j_] = c_ >= 0 ? d_ : 0xFFFFu; } }
-#define PL_PREFETCH_B() { const double *lut_ = call_g->lut; \
+#define PL_PREFETCH_B() { const FS_GLOBAL double *lut_ = call_g->lut; \
   _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) { const unsigned a_ = ppl[j_] & 0xFFFFu, b_ = ppl[j_] >> 16, d_ = ppl2[j_]; \
     const double t0_ = lut_[a_ < 4096u ? a_ : 0u], t1_ = lut_[b_ < 4096u ? b_ : 0u], t2_ = lut_[d_ < 4096u ? d_ : 0u]; \
     const bool miss_ = a_ == 0xFFFFu && b_ == 0xFFFFu && d_ == 0xFFFFu; \
@@ -451,10 +457,10 @@ struct fs_call_args {
 // rows -> [site][VCF column][genotype], coalesced; FGT likewise from the byte table
 #define CALL_ELEM(e_) { const int s_ = (int)FS_UMULHI((unsigned)(e_), mg_), r_ = (e_) - s_ * w_, k_ = (r_ * 171) >> 9; \
     __builtin_nontemporal_store(s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)], g_ + (e_)); }
-#define STAGE_OUT_CALL(Gp) { const int w_ = 3 * call_g->n_seq; const unsigned mg_ = call_g->magic_w; double *g_ = (Gp) + site0 * w_; \
+#define STAGE_OUT_CALL(Gp) { const int w_ = 3 * call_g->n_seq; const unsigned mg_ = call_g->magic_w; FS_GLOBAL double *g_ = (Gp) + site0 * w_; \
   if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < 3 * NMEM; ++j_) if (j_ < w_) CALL_ELEM(tid + j_ * BT) } \
   else { for (int e = tid; e < ns * w_; e += BT) CALL_ELEM(e) } }
-#define STAGE_FGT(Gp) { const int n_seq = call_g->n_seq; const unsigned mg_ = call_g->magic_n; signed char *g_ = (Gp) + site0 * n_seq; \
+#define STAGE_FGT(Gp) { const int n_seq = call_g->n_seq; const unsigned mg_ = call_g->magic_n; FS_GLOBAL signed char *g_ = (Gp) + site0 * n_seq; \
   for (int it_ = tid; it_ < ns * n_seq; it_ += BT) { const int s_ = mg_ ? (int)FS_UMULHI((unsigned)it_, mg_) : it_, k_ = it_ - s_ * n_seq; \
     g_[it_] = s_fgt[s_ * NMEM + s_seq[k_]]; } }
 )");

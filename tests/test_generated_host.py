@@ -36,6 +36,7 @@ static idx3_ threadIdx{0}, blockIdx{0}, gridDim{1};
 SHIM_CALL = r"""
 #include <cmath>
 #define FS_RCP(x) (1.0 / (x))
+#define FS_GLOBAL
 static inline double fs_mant_(double x) { int e; return std::frexp(x, &e); }
 static inline int fs_exp_(double x) { int e; std::frexp(x, &e); return e; }
 #define FS_FREXP_MANT(x) fs_mant_(x)
