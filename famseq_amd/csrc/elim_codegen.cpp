@@ -395,6 +395,8 @@ const std::string kCallHelpers = std::string(R"(
 #define FS_FREXP_MANT(x) __builtin_amdgcn_frexp_mant(x)
 #define FS_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
 #define FS_UMULHI(a, b) __umulhi(a, b)
+#define FS_IS_POS_FINITE(x) __builtin_amdgcn_class(x, 0x180)  /* +normal | +denormal */
+#define FS_KEEP_BRANCH() asm volatile("" ::: "memory")
 #endif
 // Pointers that reach the kernel through the argument struct are generic to the compiler, and every access
 // through them would be a flat_* instruction (counted on both vmcnt and lgkmcnt, waited for with both at 0).
@@ -428,23 +430,6 @@ struct fs_call_args {
   const FS_GLOBAL unsigned short *p_ = call_g->pl + site0 * n_seq * 3; \
   if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) PL_ITEM(tid + j_ * BT) } \
   else { for (int it_ = tid; it_ < ns * NMEM; it_ += BT) PL_ITEM(it_) } }
-// The next chunk's packed PLs, fetched ahead in two steps that each sit behind a block of arithmetic (the
-// look-ups depend on the PLs): PL_PREFETCH_A issues the 2-byte loads of this lane's NMEM items, PL_PREFETCH_B
-// turns them into table look-ups whose values wait in registers (prel) until the next chunk's STAGE_PRE_PL
-// writes them into the rows.  Branch-free (clamped indices, selects afterwards): all of a lane's loads are in
-// flight together.  Without this the call path spent 47 % of its wave cycles in s_waitcnt (SQ_WAIT_ANY).
-#define PL_PREFETCH_A() { const int n_seq = call_g->n_seq; const FS_GLOBAL unsigned short *p_ = call_g->pl + (site0 + BT) * n_seq * 3; \
-  _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) { const int it_ = tid + j_ * BT, s_ = it_ / NMEM, i_ = it_ - s_ * NMEM, c_ = s_col[i_]; \
-    const FS_GLOBAL unsigned short *q_ = p_ + (s_ * n_seq + (c_ >= 0 ? c_ : 0)) * 3; const unsigned a_ = q_[0], b_ = q_[1], d_ = q_[2]; \
-    ppl[j_] = c_ >= 0 ? (a_ | (b_ << 16)) : 0xFFFFFFFFu; ppl2[j_] = c_ >= 0 ? d_ : 0xFFFFu; } }
-#define PL_PREFETCH_B() { const FS_GLOBAL double *lut_ = call_g->lut; \
-  _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) { const unsigned a_ = ppl[j_] & 0xFFFFu, b_ = ppl[j_] >> 16, d_ = ppl2[j_]; \
-    const double t0_ = lut_[a_ < 4096u ? a_ : 0u], t1_ = lut_[b_ < 4096u ? b_ : 0u], t2_ = lut_[d_ < 4096u ? d_ : 0u]; \
-    const bool miss_ = a_ == 0xFFFFu && b_ == 0xFFFFu && d_ == 0xFFFFu; \
-    prel[3 * j_] = miss_ ? 1.0 : (a_ < 4096u ? t0_ : 0.0); prel[3 * j_ + 1] = miss_ ? 1.0 : (b_ < 4096u ? t1_ : 0.0); \
-    prel[3 * j_ + 2] = miss_ ? 1.0 : (d_ < 4096u ? t2_ : 0.0); } }
-#define STAGE_PRE_PL() { _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) { const int it_ = tid + j_ * BT, s_ = it_ / NMEM, i_ = it_ - s_ * NMEM; \
-    double *w_ = s_io + s_ * ROW + 3 * i_; w_[0] = prel[3 * j_]; w_[1] = prel[3 * j_ + 1]; w_[2] = prel[3 * j_ + 2]; } }
 // The lane's row holds probabilities (single or BN posterior, NaN where the site failed): turn it in place
 // into what is printed, fabs(-10 log10 p), and note the arg-max genotype of every member (strict '<' from
 // -1: ties to the lower genotype, NaN rows give -1).  3 N independent logarithms per lane: plenty of ILP.
@@ -614,8 +599,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
                     "  __shared__ int s_col[NMEM], s_seq[NMEM];  // member -> VCF column or -1; VCF column -> member\n"
                     "  __shared__ signed char s_fgt[BT * NMEM];  // arg-max genotype of every member of every site of the chunk\n"
                     "  for (int i = tid; i < NMEM; i += BT) { s_col[i] = call_g->col[i]; s_seq[i] = i < call_g->n_seq ? call_g->seq[i] : 0; }\n"
-                    "  unsigned ppl[NMEM], ppl2[NMEM];  // the next chunk's packed PLs of this lane's items ...\n"
-                    "  double prel[3 * NMEM];           // ... and then their likelihoods, fetched ahead\n"
+
                   : "")
     << (strided ? "  for (long ch = c_lo; ch < c_hi; ch += gridDim.x) {\n" : "  for (long ch = c_lo; ch < c_hi; ++ch) {\n")
     << "    const long site0 = ch * BT;\n"
@@ -630,7 +614,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
   } else {
-    s << (call_mode ? "    if (have_pre) { STAGE_PRE_PL(); } else { STAGE_IN_ANY(); }\n" : "    STAGE_IN(lk_g);\n");
+    s << (call_mode ? "    STAGE_IN_ANY();\n" : "    STAGE_IN(lk_g);\n");
   }
   s << "    LDS_BARRIER();\n"
     << "    const int fl = (tid < ns && flags_g) ? (flags_g[site0 + tid] & 3) : 0;\n"
@@ -654,9 +638,6 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << (call_mode ? "      ROW_TO_CALL();  // the BN posterior as printed (FPP) and the genotype call\n" : "")
       << "    }\n";
-    if (call_mode)  // the next chunk's PLs: fetched while this chunk's last rows are stored
-      s << "    have_pre = packed_in && ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are fetched ahead\n"
-        << "    if (have_pre) { PL_PREFETCH_A(); PL_PREFETCH_B(); }\n";
     if (prefetch && !early)
       s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
@@ -692,13 +673,9 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       // chunk's two output phases run (the barriers below do not wait for vmcnt)
       s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
       << "    if (have_pre) { PREFETCH(lk_g); }\n";
-    if (call_mode)  // the next chunk's PLs: the 2-byte loads go out here, behind them the single posterior's arithmetic ...
-      s << "    have_pre = packed_in && ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // only whole chunks are fetched ahead\n"
-        << "    if (have_pre) { PL_PREFETCH_A(); }\n";
     single_pass(false, true);  // now the single posterior may take the row over
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
-      << (call_mode ? "    ROW_TO_CALL();  // the single posterior as printed (GPP) and its arg-max (FGT of shortcut sites)\n"
-                      "    if (have_pre) { PL_PREFETCH_B(); }  // ... and the table look-ups here, in flight through the output phases\n" : "")
+      << (call_mode ? "    ROW_TO_CALL();  // the single posterior as printed (GPP) and its arg-max (FGT of shortcut sites)\n" : "")
       << "    LDS_BARRIER();\n"
       << (call_mode ? "    if (call_g->gpp) { STAGE_OUT_CALL(call_g->gpp); }\n" : "    if (single_g) { STAGE_OUT(single_g); }\n")
       << "    LDS_BARRIER();  // single rows are stored; sites that ran the full computation overwrite theirs\n"

@@ -62,6 +62,8 @@ __global__ __launch_bounds__(256) void unpack_pl16_kernel(const uint16_t *__rest
 #define FS_RCP(x) __builtin_amdgcn_rcp(x)
 #define FS_FREXP_MANT(x) __builtin_amdgcn_frexp_mant(x)
 #define FS_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
+#define FS_IS_POS_FINITE(x) __builtin_amdgcn_class(x, 0x180)
+#define FS_KEEP_BRANCH() asm volatile("" ::: "memory")
 #define FS_PHRED_DEF(...) __VA_ARGS__
 #include "phred_src.h"
 __device__ __forceinline__ double phred(double p) { return fs_phred(p); }

@@ -6,8 +6,10 @@
 // Exponent and mantissa split, m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh((m - 1) / (m + 1)) by its series
 // to s^23 (|s| < 0.172), quotient from v_rcp_f64 + one Newton step + one residual correction.  Relative
 // error < 1e-15 in 40 instructions (ocml's log10: 111, for a last half ulp that the 6 printed digits
-// never see).  0 -> 99999; NaN or negative -> NaN.
-// Needs FS_RCP / FS_FREXP_MANT / FS_FREXP_EXP (device builtins; the host test shims them).
+// never see).  0 -> 99999; NaN or negative -> NaN.  Everything but a positive finite p is rare: ONE class test
+// (v_cmp_class_f64) and the special values behind a real branch (FS_KEEP_BRANCH keeps hipcc from turning it back
+// into nine compare-and-select instructions per logarithm).
+// Needs FS_RCP / FS_FREXP_MANT / FS_FREXP_EXP / FS_IS_POS_FINITE / FS_KEEP_BRANCH (device builtins; the host test shims them).
 FS_PHRED_DEF(
 static __device__ __forceinline__ double fs_phred(double p) {
   const double m0 = FS_FREXP_MANT(p);
@@ -35,9 +37,10 @@ static __device__ __forceinline__ double fs_phred(double p) {
   t = __builtin_fma(t, z, 2.0 / 3);
   const double ln = __builtin_fma(s * z, t, s + s);
   double q = __builtin_fabs(__builtin_fma((double)e, -3.0102999566398120, ln * -4.3429448190325175));
-  if (p == 0.0) q = 99999.0;
-  if (p == __builtin_inf()) q = p;
-  if (!(p >= 0.0)) q = __builtin_nan("");
+  if (!FS_IS_POS_FINITE(p)) {
+    FS_KEEP_BRANCH();
+    q = p == 0.0 ? 99999.0 : (p == __builtin_inf() ? p : __builtin_nan(""));
+  }
   return q;
 }
 )
