@@ -408,6 +408,7 @@ const std::string kCallHelpers = std::string(R"(
 // The call path's arguments sit in one small struct in device memory behind a pointer that is null on the
 // plain path: its fields are fetched (scalar loads) only inside the stages that use them.  As ten more
 // kernel arguments they stayed live in SGPRs for the whole kernel and pushed the arithmetic into scratch.
+typedef double fs_v2d __attribute__((ext_vector_type(2)));
 struct fs_call_args {
   const FS_GLOBAL unsigned short *pl;  // [n_sites][n_seq][3] packed PLs, or null: fp64 likelihood rows come in as usual
   const FS_GLOBAL double *lut;         // pow(10, -k / 10), k < 4096
@@ -442,8 +443,15 @@ struct fs_call_args {
 // rows -> [site][VCF column][genotype], coalesced; FGT likewise from the byte table
 #define CALL_ELEM(e_) { const int s_ = (int)FS_UMULHI((unsigned)(e_), mg_), r_ = (e_) - s_ * w_, k_ = (r_ * 171) >> 9; \
     __builtin_nontemporal_store(s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)], g_ + (e_)); }
+// two neighbouring elements per lane and store (16 B; the second may be the next site's first)
+#define CALL_PAIR(p2_) { const int e_ = 2 * (p2_), s_ = (int)FS_UMULHI((unsigned)e_, mg_), r_ = e_ - s_ * w_, k_ = (r_ * 171) >> 9; \
+    const int w1_ = r_ + 1 == w_, s1_ = s_ + w1_, r1_ = w1_ ? 0 : r_ + 1, k1_ = (r1_ * 171) >> 9; \
+    fs_v2d v_; v_.x = s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)]; v_.y = s_io[s1_ * ROW + 3 * s_seq[k1_] + (r1_ - 3 * k1_)]; \
+    __builtin_nontemporal_store(v_, (FS_GLOBAL fs_v2d *)(g_ + e_)); }
 #define STAGE_OUT_CALL(Gp) { const int w_ = 3 * call_g->n_seq; const unsigned mg_ = call_g->magic_w; FS_GLOBAL double *g_ = (Gp) + site0 * w_; \
-  if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < 3 * NMEM; ++j_) if (j_ < w_) CALL_ELEM(tid + j_ * BT) } \
+  if (whole && (BT & 1) == 0 && ((unsigned long)g_ & 15) == 0) { const int half_ = BT / 2 * w_; \
+    _Pragma("unroll") for (int j_ = 0; j_ < (3 * NMEM + 1) / 2; ++j_) if (tid + j_ * BT < half_) CALL_PAIR(tid + j_ * BT) } \
+  else if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < 3 * NMEM; ++j_) if (j_ < w_) CALL_ELEM(tid + j_ * BT) } \
   else { for (int e = tid; e < ns * w_; e += BT) CALL_ELEM(e) } }
 #define STAGE_FGT(Gp) { const int n_seq = call_g->n_seq; const unsigned mg_ = call_g->magic_n; FS_GLOBAL signed char *g_ = (Gp) + site0 * n_seq; \
   for (int it_ = tid; it_ < ns * n_seq; it_ += BT) { const int s_ = mg_ ? (int)FS_UMULHI((unsigned)it_, mg_) : it_, k_ = it_ - s_ * n_seq; \

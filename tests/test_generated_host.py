@@ -36,6 +36,7 @@ static idx3_ threadIdx{0}, blockIdx{0}, gridDim{1};
 SHIM_CALL = r"""
 #include <cmath>
 #define FS_RCP(x) (1.0 / (x))
+struct fs_v2d { double x, y; };
 #define FS_IS_POS_FINITE(x) ((x) > 0 && (x) < INFINITY)
 #define FS_KEEP_BRANCH() (void)0
 #define FS_GLOBAL
@@ -82,6 +83,7 @@ extern "C" void famseq_enum_lane(const double *lk, const unsigned char *fl, doub
 
 def host_source(src: str, threads=False) -> str:
     src = re.sub(r"#define FS_KEEP_BRANCH\(\) asm.*", "", src)  # device default; the host shim has its own
+    src = src.replace("typedef double fs_v2d __attribute__((ext_vector_type(2)));", "")
     src = src.replace("__builtin_amdgcn_sched_barrier(0);", "")  # scheduling pins: no code on the device either
     if threads:
         src = src.replace("#include <hip/hip_runtime.h>", SHIM_THREADS)
@@ -420,7 +422,7 @@ def _threaded_call_kernel(model, elim, bt, cache, monkeypatch):
     reads_rows = "lg[" in src
     shim = SHIM_THREADS.replace("#define famseq_enum_lane famseq_enum_lane_one_thread", "#define %s kernel_one_thread_" % entry)
     shim += SHIM_CALL + "#define __builtin_amdgcn_ballot_w64(p) ((unsigned long)(p))\n"
-    src = re.sub(r"#define FS_KEEP_BRANCH\(\) asm.*", "", src)
+    src = re.sub(r"#define FS_KEEP_BRANCH\(\) asm.*", "", src).replace("typedef double fs_v2d __attribute__((ext_vector_type(2)));", "")
     src = src.replace("#include <hip/hip_runtime.h>", shim).replace("__builtin_amdgcn_sched_barrier(0);", "")
     src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() pthread_barrier_wait(&wg_barrier_)", src)
     src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "").replace("__attribute__((address_space(3)))", "")
