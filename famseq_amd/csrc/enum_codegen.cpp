@@ -393,6 +393,18 @@ class Gen {
   // (index into outer_, -1 = none): each bucket is emitted at the top of that loop's body, so a
   // table is rebuilt only when a digit it depends on changes.
   std::vector<std::string> bucket_;  // [outer position + 1]
+  // Lazy tables (FAMSEQ_LANE_LAZY, an experiment that is OFF: measured slower): entries (factor tables of
+  // prefix levels, block sums) that depend on the FIRST unrolled member's digit only, and are rebuilt in the
+  // innermost loop anyway, are not built at the top of the block for all three digits but inside that
+  // digit's part of the unrolled tree: a third of them is live at a time.  At ten members that is 14
+  // doubles = 28 VGPRs — the whole of the spill, which the eager form reloads from scratch inside the
+  // block (10 scratch loads per outer step): scratch goes from 108 B to 0.  But the LDS reads behind the
+  // table statements then sit in the middle of the block: 11.1 ms per 4 M sites against 10.3 (built one
+  // digit ahead: 10.6, scratch back at 100 B).  The block total Q0 is summed as the parts go by (same FMA
+  // order), so the results are bit-identical either way.
+  bool lazy0_ = false, lazy_ahead_ = false;
+  std::string lazy0_stmt_[3];
+  bool q0_incremental_ = false;
 
   // where the block's table statements read unrolled member p's likelihood from
   std::string lk_src(int p, int g) const {
@@ -427,6 +439,26 @@ class Gen {
     const std::vector<int> wb = table_buckets();  // bucket of level k's factor table
     std::vector<int> qb(nu_ + 1, -1);             // ... and of its block sums
     for (int k = nu_ - 1; k >= 0; --k) qb[k] = std::max(qb[k + 1], wb[k]);
+    // which levels' tables / block sums are lazy (see lazy0_): a prefix level k >= 1 whose block sums depend on
+    // level 0's digit only and sit in the innermost loop; the chain must be unbroken from level 1 on, because
+    // the (eager) sums of a level use those of the next
+    const int innermost = (int)outer_.size() - 1;
+    const int n_prefix = nu_ - (sl_ >= 2 ? sl_ : 1);  // levels above the (super-)leaf
+    std::vector<char> lazy_q(nu_ + 1, 0), lazy_w(nu_ + 1, 0);
+    if (const char *e = std::getenv("FAMSEQ_LANE_LAZY")) {  // tuning aid: 0 eager, 1 lazy, 2 lazy one digit ahead
+      lazy0_ = std::atoi(e) != 0;
+      lazy_ahead_ = std::atoi(e) == 2;
+    }
+    if (lazy0_ && innermost >= 0 && n_prefix >= 2)
+      for (int k = 1; k < n_prefix; ++k) {
+        if (!(dep_[k].size() == 1 && dep_[k][0] == 0 && qb[k] == innermost)) break;
+        lazy_q[k] = 1;
+        const int p = s_.unrolled[k];
+        const bool mu = m_.mother[p] >= 0 && s_.upos[m_.mother[p]] >= 0, fu = m_.mother[p] >= 0 && s_.upos[m_.father[p]] >= 0;
+        const bool m0 = mu && s_.upos[m_.mother[p]] == 0, f0 = fu && s_.upos[m_.father[p]] == 0;
+        lazy_w[k] = wb[k] == innermost && (mu + fu) == 1 && (m0 || f0);
+      }
+    q0_incremental_ = lazy_q[1];
     for (int k = 0; k < nu_; ++k) {
       std::ostringstream o;
       const int p = s_.unrolled[k];
@@ -441,7 +473,21 @@ class Gen {
             o << ind << "const double w" << p << "_" << g << suffix << " = tcf["
               << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * " << lk_src(p, g) << ";\n";
         }
+      if (lazy_w[k]) continue;  // emitted per digit of the first unrolled member (below)
       bucket_[wb[k] + 1] += o.str();
+    }
+    for (int k = 1; k < nu_; ++k) {
+      if (!lazy_w[k]) continue;
+      const int p = s_.unrolled[k];
+      const bool mu = s_.upos[m_.mother[p]] == 0, fu = s_.upos[m_.father[p]] == 0;  // exactly one of them is level 0
+      for (int d = 0; d < 3; ++d) {
+        std::ostringstream o;
+        const std::string suffix = (mu ? "m" : "f") + num(d);
+        for (int g = 0; g < 3; ++g)
+          o << ind << "const double w" << p << "_" << g << suffix << " = tcf[" << t_index(p, num(g), mu ? d : -1, fu ? d : -1)
+            << "] * " << lk_src(p, g) << ";\n";
+        lazy0_stmt_[d] += o.str();
+      }
     }
     // block sums, deepest level first
     for (int k = nu_ - 1; k >= 0; --k) {
@@ -461,7 +507,9 @@ class Gen {
           if (q == "1.0") e = e.empty() ? w : "(" + e + " + " + w + ")";
           else e = e.empty() ? "(" + w + " * " + q + ")" : "__builtin_fma(" + w + ", " + q + ", " + e + ")";
         }
-        o << ind << "const double " << q_name(k, dig) << " = " << e << ";\n";
+        if (k == 0 && q0_incremental_) continue;  // summed inside the block as level 0's digits go by
+        if (lazy_q[k]) lazy0_stmt_[dig[0]] += ind + "const double " + q_name(k, dig) + " = " + e + ";\n";
+        else o << ind << "const double " << q_name(k, dig) << " = " << e << ";\n";
       }
       bucket_[qb[k] + 1] += o.str();
     }
@@ -578,6 +626,21 @@ class Gen {
     }
     for (int g = 0; g < 3; ++g) {
       dig[k] = g;
+      if (k == 0) {
+        // one digit ahead: the LDS reads behind these statements return while the previous digit's part of the
+        // tree is computed (built at the head of their own part they stalled it: 11.1 vs 10.3 ms per 4 M sites)
+        if (lazy_ahead_) {
+          if (g == 0) o_ << lazy0_stmt_[0];
+          if (g < 2) o_ << lazy0_stmt_[g + 1];
+        } else {
+          o_ << lazy0_stmt_[g];
+        }
+        if (q0_incremental_) {  // the block total, in the order the eager form adds it
+          const std::string w = w_name(0, g, dig), q = q_name(1, dig);
+          if (g == 0) o_ << ind << "double Q0i = " << w << " * " << q << ";\n";
+          else o_ << ind << "Q0i = __builtin_fma(" << w << ", " << q << ", Q0i);\n";
+        }
+      }
       const std::string pg = "p" + num(uid_++);
       o_ << ind << "double " << pg << " = " << P << " * " << w_name(k, g, dig) << ";\n"
          << ind << "b" << p << "_" << g << " = __builtin_fma(" << pg << ", " << q_name(k + 1, dig) << ", b" << p << "_" << g
@@ -594,8 +657,9 @@ class Gen {
     const std::string in2 = ind + "  ";
     std::vector<int> dig(nu_, 0);
     o_ << in2 << "double Pb = " << P << ";\n";
-    if (!acc_parent.empty()) o_ << in2 << acc_parent << " += Pb * " << q_name(0, dig) << ";\n";
+    if (!acc_parent.empty() && !q0_incremental_) o_ << in2 << acc_parent << " += Pb * " << q_name(0, dig) << ";\n";
     level(0, "Pb", dig, in2);
+    if (!acc_parent.empty() && q0_incremental_) o_ << in2 << acc_parent << " += Pb * Q0i;\n";
     o_ << ind << "}\n";
   }
 };
