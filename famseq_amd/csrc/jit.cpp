@@ -137,6 +137,16 @@ std::string jit_compile(const std::string &source, int *scratch_bytes, bool note
       }
     }
   }
+  if (std::getenv("FAMSEQ_JIT_SOURCE_ONLY")) {
+    // test aid (tests/test_generated_host.py compiles the generated SOURCE for the host): keep the source,
+    // leave an empty placeholder where the code object would be, do not run the compiler.  A placeholder
+    // never loads (hipModuleLoad fails loudly), so this cannot turn into a silent product path.
+    std::ofstream((dir + "/" + name + ".hip").c_str()) << source;
+    std::ofstream((dir + "/" + name + ".res").c_str()) << 0 << "\n";
+    std::ofstream(obj.c_str()).flush();
+    if (scratch_bytes) *scratch_bytes = 0;
+    return obj;
+  }
   if (const char *why = profiler_env())
     throw std::runtime_error(std::string("kernel ") + name + " is not in the cache (" + dir + ") and a profiler is attached ($" +
                              why + "): build it outside the profiler first (a plan-only ctx with the same options, "

@@ -168,7 +168,7 @@ def build_host_kernel(model, kind, tmp_path, monkeypatch):
     cache = tmp_path / ("cache_" + kind)
     cache.mkdir(exist_ok=True)
     for k, v in dict(FAMSEQ_KERNEL_CACHE=str(cache), FAMSEQ_KEEP_SRC="1", FAMSEQ_LANE_BT="1", FAMSEQ_ELIM_BT="1",
-                     FAMSEQ_LANE_MINWAVES="1").items():
+                     FAMSEQ_LANE_MINWAVES="1", FAMSEQ_JIT_SOURCE_ONLY="1").items():  # the source is what is tested: no hipcc
         monkeypatch.setenv(k, v)
     ctx = fs.Context(model, device=-1)
     if kind.startswith("group"):  # lanes-per-site mode: "group<d>" = 3^d lanes per site, two sites per workgroup
@@ -393,6 +393,7 @@ def test_packed_input_is_refused_to_a_kernel_that_rereads_fp64_rows(tmp_path, mo
 
     monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
     monkeypatch.setenv("FAMSEQ_KEEP_SRC", "1")
+    monkeypatch.setenv("FAMSEQ_JIT_SOURCE_ONLY", "1")
     seen = set()
     for seed in (2, 8, 10):
         _, ped, mu = soak_pedigree(seed)
@@ -411,7 +412,7 @@ def _threaded_call_kernel(model, elim, bt, cache, monkeypatch):
     """Call-path form generated for `bt` lanes per workgroup, its lanes as host threads (the workgroup
     barrier a pthread barrier, LDS the shared statics)."""
     for k, v in dict(FAMSEQ_KERNEL_CACHE=str(cache), FAMSEQ_KEEP_SRC="1", FAMSEQ_LANE_BT=str(bt), FAMSEQ_ELIM_BT=str(bt),
-                     FAMSEQ_LANE_MINWAVES="1").items():
+                     FAMSEQ_LANE_MINWAVES="1", FAMSEQ_JIT_SOURCE_ONLY="1").items():
         monkeypatch.setenv(k, v)
     ctx = fs.Context(model, device=-1)
     ctx.set_option("call_kernels", 1)
