@@ -46,3 +46,31 @@ def test_profile_evidence_is_committed():
     assert any(f.startswith("kernel_stats") for f in os.listdir(latest))
     t = json.load(open(os.path.join(prof, "hbm_traffic_ped10.json")))
     assert t["sites_per_launch"] > 0 and t["bytes_per_launch"] >= t["algorithmic_bytes_per_launch"] * 0.9
+
+
+def test_bench_launches_ranks_itself_or_says_why_not():
+    """`python bench.py --gpus N` as a plain command is the driver's multi-GPU shape: outside
+    torch.distributed.run bench.py starts the ranks itself (tests/test_gpu_multi.py runs that on the GPU box).
+    Without enough GPUs it must say so before launching anything — not the round-1 "needs a
+    torch.distributed.run launch" refusal, and not a hang."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        return  # a real multi-GPU host: the GPU suite covers it
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and "torch.distributed.run launch" not in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_warm_only_builds_the_kernels_without_a_gpu(tmp_path):
+    """bench.py --warm-only (what the profiling scripts run before rocprofv3): plan-only contexts, kernels
+    found in (or compiled into) the cache, no GPU call."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--warm-only", "--workload", "ped5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "warm: ped5" in r.stdout and ".hsaco" in r.stdout
