@@ -128,6 +128,10 @@ __device__ __forceinline__ void load_low(double (&v)[L][3], double (&R)[L], doub
   Sall = run;
 }
 
+// __launch_bounds__(768): the largest team (3^6 = 729 lanes) needs a 768-thread workgroup.  For the usual
+// 256-thread launch this is not a looser budget than it needs: 768 threads = 3 waves per SIMD = 168 VGPRs,
+// exactly the occupancy the kernel runs at (3 workgroups of 256 per CU; LDS allows no more), i.e. the same
+// register budget as __launch_bounds__(256, 3) would give.
 template <int L, bool LOWINV>
 __global__ __launch_bounds__(768) void bn_enum_kernel(const KParams P, const uint32_t *__restrict__ img,
                                                        const double *__restrict__ tc_g, const long n_sites,
