@@ -495,7 +495,7 @@ std::string single_posterior_statements(const famseq_model &m, bool flags_pass, 
 //                   BEFORE the single posterior takes over the row.
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
-                         bool chrx_loop, int row_doubles, bool call_mode) {
+                         bool chrx_loop, int row_doubles, bool call_mode, bool lane_body) {
   // ROW: the lane's LDS row, W3 doubles padded to an odd count (conflict-free ds_read_b64); a
   // generator may ask for more (spare slots it uses itself), odd again
   const int N = m.n_members, W3 = 3 * N, ROW = (row_doubles > 0 ? row_doubles : W3) | 1;
@@ -674,7 +674,11 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
         << "        if (mine_) {\n"
         << body << "        }\n      }\n    }\n";
     } else {
-      s << "    if (full && !single_fail) {\n" << body << "    }\n";
+      s << "    if (full && !single_fail) {\n"
+        << (lane_body ? "      double *srow = row + W3;  // the enumeration's scratch slots, behind the likelihoods\n"
+                        "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;  // this lane's row in global memory (fp64 input only)\n"
+                        "      (void)srow; (void)lg;\n" : "")
+        << body << "    }\n";
     }
     if (prefetch && !early)
       // software prefetch: issue the next chunk's loads now; they stay in flight while this

@@ -27,7 +27,7 @@ extern const char kCallArgs[];     // ... and the kernel arguments that go with 
 std::string single_posterior_statements(const famseq_model &m, bool flags_pass, bool store, bool fence_single);
 std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
-                         bool chrx_loop = false, int row_doubles = 0, bool call_mode = false);
+                         bool chrx_loop = false, int row_doubles = 0, bool call_mode = false, bool lane_body = false);
 
 }  // namespace famseq
 #endif

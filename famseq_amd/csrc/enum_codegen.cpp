@@ -114,8 +114,12 @@ class Gen {
  public:
   // fixed: the `fixed` outermost looped members do not loop — their digits come from the lane's
   // position in its group (fx0, fx1, ...: lanes-per-site mode, 3^fixed lanes share a site)
-  Gen(const famseq_model &m, const Shape &s, int row_len, int fixed = 0)
-      : m_(m), s_(s), nu_((int)s.unrolled.size()), row_len_(row_len), fixed_(fixed), outer_(s.outer) {}
+  // late: the small-pedigree form — the lane's row keeps the input likelihoods (the shell reads them from
+  // LDS and turns them into the single posterior only after this body), so the body's scratch slots live
+  // behind them (srow = row + W3) and the normalised marginals go to registers q[] instead of the row
+  Gen(const famseq_model &m, const Shape &s, int row_len, int fixed = 0, bool late = false)
+      : m_(m), s_(s), nu_((int)s.unrolled.size()), row_len_(row_len), fixed_(fixed), S_(late ? "srow" : "row"),
+        O_(late ? "q" : "row"), outer_(s.outer) {}
 
   // Lanes-per-site mode, last step (the group's first lane, after the column sums): normalise,
   // failure rule (family.cpp:943-954).
@@ -182,8 +186,8 @@ class Gen {
     // unrolled block free of scratch traffic.
     for (int k = 0; k < no; ++k)
       for (int g = 0; g < 3; ++g) {
-        o_ << "      row[" << 3 * k + g << "] = 0;\n";
-        if (l_in_lds_) o_ << "      row[" << 3 * no + 3 * k + g << "] = l" << outer_[k] << "_" << g << ";\n";
+        o_ << "      " << S_ << "[" << 3 * k + g << "] = 0;\n";
+        if (l_in_lds_) o_ << "      " << S_ << "[" << 3 * no + 3 * k + g << "] = l" << outer_[k] << "_" << g << ";\n";
       }
     // The unrolled members' likelihoods are needed only where their tables are rebuilt (outer loop
     // levels).  What is left of the LDS row holds them for the members whose tables sit in the
@@ -201,7 +205,7 @@ class Gen {
       for (int k : order) {
         if (next + 3 > row_len) break;
         lds_slot_[s_.unrolled[k]] = next;
-        for (int g = 0; g < 3; ++g) o_ << "      row[" << next + g << "] = l" << s_.unrolled[k] << "_" << g << ";\n";
+        for (int g = 0; g < 3; ++g) o_ << "      " << S_ << "[" << next + g << "] = l" << s_.unrolled[k] << "_" << g << ";\n";
         next += 3;
       }
     }
@@ -226,8 +230,8 @@ class Gen {
     o_ << bucket_[0];
     outer_level(0, "P_root", "");
     for (int k = 0; k < no; ++k)
-      o_ << "      const double b" << outer_[k] << "_0 = row[" << 3 * k << "], b" << outer_[k] << "_1 = row[" << 3 * k + 1
-         << "], b" << outer_[k] << "_2 = row[" << 3 * k + 2 << "];\n";
+      o_ << "      const double b" << outer_[k] << "_0 = " << S_ << "[" << 3 * k << "], b" << outer_[k] << "_1 = " << S_ << "[" << 3 * k + 1
+         << "], b" << outer_[k] << "_2 = " << S_ << "[" << 3 * k + 2 << "];\n";
     if (joint_) {  // the super-leaf members' marginals: sums of the joint accumulators over the other digits
       std::vector<int> dig(nu_, 0);
       for (int j = 0; j < sl_; ++j)
@@ -253,7 +257,7 @@ class Gen {
     }
     for (int p = 0; p < s_.N; ++p)
       o_ << "      { const double s = (b" << p << "_0 + b" << p << "_1) + b" << p << "_2; if (s <= 0) bn_fail = true;\n"
-         << "        row[" << 3 * p << "] = b" << p << "_0 / s; row[" << 3 * p + 1 << "] = b" << p << "_1 / s; row["
+         << "        " << O_ << "[" << 3 * p << "] = b" << p << "_0 / s; " << O_ << "[" << 3 * p + 1 << "] = b" << p << "_1 / s; " << O_ << "["
          << 3 * p + 2 << "] = b" << p << "_2 / s; }\n";
     return o_.str();
   }
@@ -264,6 +268,7 @@ class Gen {
   const int nu_;
   const int row_len_;  // doubles in the lane's LDS row (>= 3N, odd)
   const int fixed_;    // outermost looped members whose digit is the lane's (lanes-per-site mode)
+  const std::string S_, O_;  // the body's scratch array and where the normalised marginals go
   std::vector<int> outer_;  // looped members, outermost first
   std::ostringstream o_;
   int uid_ = 0;
@@ -297,7 +302,7 @@ class Gen {
     const int p = outer_[k];
     const int no = (int)outer_.size();
     const std::string g = "g" + num(p), ind(6 + 2 * k, ' ');
-    const std::string lk_g = l_in_lds_ ? "row[" + num(3 * no + 3 * (int)k) + " + " + g + "]"
+    const std::string lk_g = l_in_lds_ ? S_ + "[" + num(3 * no + 3 * (int)k) + " + " + g + "]"
                                        : "(" + g + " == 0 ? l" + num(p) + "_0 : (" + g + " == 1 ? l" + num(p) + "_1 : l" + num(p) + "_2))";
     if ((int)k < fixed_)
       o_ << ind << "{ const int " << g << " = fx" << k << ";  // one digit per lane of the group\n";
@@ -309,7 +314,7 @@ class Gen {
        << ind << "  double acc" << p << " = 0;\n"
        << bucket_[k + 1];
     outer_level(k + 1, "P" + num(p), "acc" + num(p));
-    o_ << ind << "  row[" << 3 * (int)k << " + " << g << "] += acc" << p << ";\n";
+    o_ << ind << "  " << S_ << "[" << 3 * (int)k << " + " << g << "] += acc" << p << ";\n";
     if (!acc_parent.empty()) o_ << ind << "  " << acc_parent << " += acc" << p << ";\n";
     o_ << ind << "}\n";
   }
@@ -409,7 +414,7 @@ class Gen {
   // where the block's table statements read unrolled member p's likelihood from
   std::string lk_src(int p, int g) const {
     const auto it = lds_slot_.find(p);
-    if (it != lds_slot_.end()) return "row[" + num(it->second + g) + "]";
+    if (it != lds_slot_.end()) return S_ + "[" + num(it->second + g) + "]";
     if (before_loops_.count(p)) return "l" + num(p) + "_" + num(g);  // used once, ahead of all loops: still in registers
     return "lg[" + num(3 * p + g) + "]";
   }
@@ -802,6 +807,28 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
     // odd, two workgroups per CU (the call-path form also keeps a byte per member and lane, and two small tables)
     const int fit = ((160 * 1024 / 2 - 432 * 8 - (call_mode ? bt * m.n_members + 256 : 0)) / (bt * 8) - 1) | 1;
     if (want > row_len) row_len = std::min(want, std::max(row_len, fit));
+  }
+  // Trios and smaller (registers are plentiful): the sum-product kernel's order of phases — the whole
+  // computation first (marginals to registers), the next chunk requested, then the two outputs — instead of
+  // single posterior / store / enumeration / store: one barrier fewer and the prefetch in flight through both
+  // output phases.  The row then keeps the likelihoods until the end; scratch slots follow them.  Measured
+  // (8 M sites, tools/kernel_bench): trio 0.379 -> 0.352 ms; quad 0.600 -> 0.608 and 5 members 0.800 -> 0.803
+  // (no gain: they stay on the other order; FAMSEQ_LANE_LATE=1 forces this one for any pedigree).
+  bool late = m.n_members <= 3 && group_digits == 0;
+  if (const char *e = std::getenv("FAMSEQ_LANE_LATE")) late = std::atoi(e) != 0 && group_digits == 0;  // tuning aid
+  int scratch_len = 0;
+  if (late) {
+    int looped_tables = 0;
+    for (int p : s.unrolled)
+      if (m.mother[p] >= 0 && (s.upos[m.mother[p]] < 0 || s.upos[m.father[p]] < 0)) ++looped_tables;
+    const int fit = ((160 * 1024 / 2 - 432 * 8 - (call_mode ? bt * m.n_members + 256 : 0)) / (bt * 8) - 1) | 1;
+    const int w3 = 3 * m.n_members, room = fit - w3;
+    if (room < 3 * (int)s.outer.size()) late = false;  // not even the looped members' accumulators fit behind the row
+    else {
+      const int used = 6 * (int)s.outer.size() <= room ? 6 * (int)s.outer.size() : 3 * (int)s.outer.size();
+      scratch_len = std::min(room, used + 3 * looped_tables);
+      row_len = (w3 + scratch_len) | 1;
+    }
   }
   int group = 1;
   for (int k = 0; k < group_digits; ++k) group *= 3;
