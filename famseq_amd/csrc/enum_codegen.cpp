@@ -808,13 +808,14 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
     const int fit = ((160 * 1024 / 2 - 432 * 8 - (call_mode ? bt * m.n_members + 256 : 0)) / (bt * 8) - 1) | 1;
     if (want > row_len) row_len = std::min(want, std::max(row_len, fit));
   }
-  // Trios and smaller (registers are plentiful): the sum-product kernel's order of phases — the whole
-  // computation first (marginals to registers), the next chunk requested, then the two outputs — instead of
-  // single posterior / store / enumeration / store: one barrier fewer and the prefetch in flight through both
-  // output phases.  The row then keeps the likelihoods until the end; scratch slots follow them.  Measured
-  // (8 M sites, tools/kernel_bench): trio 0.379 -> 0.352 ms; quad 0.600 -> 0.608 and 5 members 0.800 -> 0.803
-  // (no gain: they stay on the other order; FAMSEQ_LANE_LATE=1 forces this one for any pedigree).
-  bool late = m.n_members <= 3 && group_digits == 0;
+  // An experiment that is OFF (FAMSEQ_LANE_LATE=1 turns it on): the sum-product kernel's order of phases for
+  // the enumeration too — the whole computation first (marginals to registers), the next chunk requested,
+  // then the two outputs — instead of single posterior / store / enumeration / store: one barrier fewer and
+  // the prefetch in flight through both output phases; the row keeps the likelihoods until the end, scratch
+  // slots follow them.  Measured slower (8 M sites, tools/kernel_bench, two runs): trio 0.368-0.374 -> 0.385-0.392 ms,
+  // quad 0.604-0.613 -> 0.640-0.655, 5 members 0.805-0.816 -> 0.827-0.829 (identical binaries differ by +-4 %
+  // between runs on these boxes).
+  bool late = false;
   if (const char *e = std::getenv("FAMSEQ_LANE_LATE")) late = std::atoi(e) != 0 && group_digits == 0;  // tuning aid
   int scratch_len = 0;
   if (late) {
@@ -840,8 +841,11 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
            " unrolled members, variant " + std::to_string(variant);
   int min_waves = bt / 128;
   if (const char *e = std::getenv("FAMSEQ_LANE_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
-  Gen gen(m, s, row_len, group_digits);
+  Gen gen(m, s, late ? std::max(scratch_len, 1) : row_len, group_digits, late);
   if (call_mode) what += ", call path";
+  if (late)  // regs_l = false: the shell's compute-first flow; variant 0 / 1 as below
+    return kernel_shell(m, "famseq_enum_lane", what + ", compute-first shell", gen.body(), bt, min_waves, /*regs_l=*/false, variant >= 1,
+                        /*chrx_loop=*/false, row_len, call_mode, /*lane_body=*/true);
   if (group > 1) {
     if (call_mode) throw std::runtime_error("enumeration codegen: the lanes-per-site form has no call path");
     const std::string body = gen.body();

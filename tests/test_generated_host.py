@@ -521,3 +521,23 @@ def test_call_path_forms_as_whole_workgroups(seed, tmp_path, monkeypatch):
                 b = run(pl_in=pl)
                 for x, y in zip(a, b):
                     assert np.array_equal(x, y, equal_nan=True), (seed, elim, S)
+
+
+LATE_CASES = [c for c in CASES if c.name in ("bn_synth:ped5", "bn_synth:ped5_x", "bn_synth:quad_mu0", "bn_synth:chain7", "bn_lk:fam06")]
+
+
+@pytest.mark.parametrize("case", LATE_CASES, ids=[c.name for c in LATE_CASES])
+def test_compute_first_lane_shell_on_wider_pedigrees(case, tmp_path, monkeypatch):
+    """The lane kernel's compute-first order of phases (default for trios only, FAMSEQ_LANE_LATE=1 elsewhere):
+    the enumeration's scratch slots sit behind the likelihoods in the lane's row and the marginals go through
+    registers — same fixtures, looped members included."""
+    monkeypatch.setenv("FAMSEQ_LANE_LATE", "1")
+    model = fs.make_model(case.pedigree(), **case.consts)
+    fn = build_host_kernel(model, "lane", tmp_path, monkeypatch)
+    assert "compute-first shell" in open(tmp_path / "cache_lane" / "k.cpp").read()
+    post, single, st = run_host(fn, model, case.lk, case.flags)
+    assert np.array_equal(st, case.status)
+    ok = (case.status & 3) == 0
+    assert np.array_equal(single[(case.status & 3) != 1], case.single[(case.status & 3) != 1])
+    np.testing.assert_allclose(post[ok], case.post[ok], rtol=1e-12, atol=0)
+    assert np.all(np.isnan(post[~ok]))

@@ -27,7 +27,7 @@ for src in glob.glob(tmp + "/*.hip"):
     head = open(src).readline()
     n = head.split(" for a ")[1].split("-member")[0]
     kind = "el" if "sum-product" in head else "ln"
-    variant = head.strip().split("variant ")[-1]
+    variant = head.strip().split("variant ")[-1].split(",")[0]
     base = "%s%s_%s_v%s" % (kind, n, tag, variant)
     shutil.copy(src, os.path.join(out, base + ".hip"))
     if os.path.exists(src[:-4] + ".hsaco"):
