@@ -69,7 +69,8 @@ struct famseq_ctx {
   JitKernel grp[kEnumMaxGroupDigits + 1]{};
   int grp_blocks_per_cu[kEnumMaxGroupDigits + 1] = {};
   int group_digits = -1, last_group_digits = 0;
-  int lane_reads_rows = -1;  // does the lane kernel re-read fp64 rows from global memory (unknown until asked)
+  int lane_reads_rows = -1;  // does the lane call-path kernel re-read fp64 rows from global memory (unknown until asked)
+  int lane_call_variant = -1;  // the variant jit_pick_variant took for it (the answer depends on the variant)
   int64_t lane_min_sites = 256;  // below this the compiled-in team kernel answers at once (no per-pedigree compile for tiny calls)
   // device constants
   uint32_t *d_img = nullptr;
@@ -331,7 +332,8 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
   try {
     const famseq_model &mdl = c->model;
     const std::string src = elim ? jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants)
-                                 : jit_pick_variant([&mdl](int v) { return enumgen_source(mdl, v, 0, true); }, kEnumVariants);
+                                 : jit_pick_variant([&mdl](int v) { return enumgen_source(mdl, v, 0, true); }, kEnumVariants, &c->lane_call_variant);
+    if (!elim) c->lane_reads_rows = enumgen_reads_global_rows(mdl, c->lane_call_variant) ? 1 : 0;
     if (c->device < 0) {
       k.path = jit_compile(src);
       return true;
@@ -360,12 +362,9 @@ bool launch_engine_fused(famseq_ctx *c, int64_t n_sites, const double *d_lk, con
   if (!elim) {
     const bool want_lane = c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites);
     if (!want_lane || pick_group_digits(c, n_sites) != 0) return false;
-    if (packed_in) {
-      if (c->lane_reads_rows < 0) c->lane_reads_rows = enumgen_reads_global_rows(c->model) ? 1 : 0;
-      if (c->lane_reads_rows) return false;
-    }
   }
   if (!load_call_kernel(c, elim)) return false;
+  if (!elim && packed_in && c->lane_reads_rows != 0) return false;  // (set by load_call_kernel for the variant it took)
   if (!elim) c->last_group_digits = 0;
   *err = launch_generated(c, elim ? c->elim_call.fn : c->lane_call.fn, elim ? elim_block_threads(c->model) : enumgen_block_threads(c->model),
                           elim ? c->elim_call_blocks_per_cu : c->lane_call_blocks_per_cu, n_sites, d_lk, d_flags, nullptr, nullptr,
@@ -553,13 +552,6 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
              std::to_string(enumgen_max_group_digits(c->model)) + ",\"enum_group_digits_last\":" +
              std::to_string(c->last_group_digits) + ",\"enum_group_code_objects\":[";
   for (int d = 1; d <= kEnumMaxGroupDigits; ++d) c->json += std::string(d > 1 ? "," : "") + "\"" + json_str(c->grp[d].path) + "\"";
-  if (c->lane_reads_rows < 0) {
-    try {
-      c->lane_reads_rows = enumgen_reads_global_rows(c->model) ? 1 : 0;
-    } catch (const std::exception &) {
-      c->lane_reads_rows = 0;
-    }
-  }
   c->json += "],\"enum_lane_call_code_object\":\"" + json_str(c->lane_call.path) + "\",\"elim_call_code_object\":\"" +
              json_str(c->elim_call.path) + "\",\"enum_lane_call_reads_rows\":" + std::to_string(c->lane_reads_rows) + "}";
   return c->json.c_str();

@@ -691,8 +691,8 @@ int enumgen_block_threads(const famseq_model &m) {
 
 // (asked of the call-path form: its LDS row has less room than the plain form's, so it may re-read members
 // the plain form keeps in LDS — and it is the form that can be fed packed PLs, with no fp64 rows to read)
-bool enumgen_reads_global_rows(const famseq_model &m) {
-  return enumgen_source(m, 0, 0, /*call_mode=*/true).find("lg[") != std::string::npos;
+bool enumgen_reads_global_rows(const famseq_model &m, int variant) {
+  return enumgen_source(m, variant, 0, /*call_mode=*/true).find("lg[") != std::string::npos;
 }
 
 int enumgen_max_group_digits(const famseq_model &m) {
@@ -787,7 +787,7 @@ std::string grouped_shell(const famseq_model &m, const std::string &comment, con
 }  // namespace
 
 std::string enumgen_source(const famseq_model &m, int variant, int group_digits, bool call_mode) {
-  int cap = 6;
+  int cap = (group_digits == 0 && variant < 2) ? 7 : 6;  // see kEnumVariants
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);  // tuning aid
   const Shape s = choose_shape(m, cap);
   if (s.unrolled.empty()) throw std::runtime_error("enumeration codegen: empty unrolled set");
@@ -844,16 +844,17 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
   Gen gen(m, s, late ? std::max(scratch_len, 1) : row_len, group_digits, late);
   if (call_mode) what += ", call path";
   if (late)  // regs_l = false: the shell's compute-first flow; variant 0 / 1 as below
-    return kernel_shell(m, "famseq_enum_lane", what + ", compute-first shell", gen.body(), bt, min_waves, /*regs_l=*/false, variant >= 1,
+    return kernel_shell(m, "famseq_enum_lane", what + ", compute-first shell", gen.body(), bt, min_waves, /*regs_l=*/false, (variant & 1) != 0,
                         /*chrx_loop=*/false, row_len, call_mode, /*lane_body=*/true);
+  const bool fence_single = variant & 1;
   if (group > 1) {
     if (call_mode) throw std::runtime_error("enumeration codegen: the lanes-per-site form has no call path");
     const std::string body = gen.body();
-    return grouped_shell(m, what, body, gen.reduce_body(), bt, min_waves, variant >= 1, row_len, group);
+    return grouped_shell(m, what, body, gen.reduce_body(), bt, min_waves, fence_single, row_len, group);
   }
   // regs_l: LDS-resident likelihoods measured 17% slower.  variant 0: the members of the single
   // posterior overlap, 1: fenced one from the other (fewer registers)
-  return kernel_shell(m, "famseq_enum_lane", what, gen.body(), bt, min_waves, /*regs_l=*/true, variant >= 1,
+  return kernel_shell(m, "famseq_enum_lane", what, gen.body(), bt, min_waves, /*regs_l=*/true, fence_single,
                       /*chrx_loop=*/false, row_len, call_mode);
 }
 

@@ -9,7 +9,12 @@
 namespace famseq {
 
 // HIP source of `extern "C" __global__ famseq_enum_lane(lk, flags, post, single, status, n_sites, tc, lc)`.
-constexpr int kEnumVariants = 2;  // see elim_codegen.h
+// Variants of the one-lane-per-site kernel, tried in this order by jit_pick_variant (the first that does not
+// spill wins, else the one that spills least): 0, 1 = a 7-member unrolled block (2187 configurations per outer
+// step: fewer table rebuilds; measured +1.9 % at 15 members, where it does not spill; at 10 members it spills
+// more than the 6-member block and loses the pick), 2, 3 = a 6-member block; odd = the members of the single
+// posterior fenced one from the other (fewer registers).  The lanes-per-site forms always use the 6-member block.
+constexpr int kEnumVariants = 4;
 // group_digits = d > 0: lanes-per-site mode for small batches — 3^d consecutive lanes share a site, each
 // taking one combination of the d outermost looped members' digits (d <= enumgen_max_group_digits)
 constexpr int kEnumMaxGroupDigits = 4;
@@ -18,7 +23,7 @@ int enumgen_max_group_digits(const famseq_model &m);
 // true when the call-path form of the one-lane-per-site kernel re-reads some members' likelihoods from the
 // fp64 rows in global memory inside its loops (wide pedigrees whose LDS row cannot hold them): such a kernel
 // must be given fp64 input (lk_g non-null), never packed PLs
-bool enumgen_reads_global_rows(const famseq_model &m);
+bool enumgen_reads_global_rows(const famseq_model &m, int variant);
 int enumgen_sites_per_chunk(const famseq_model &m, int group_digits);  // sites a workgroup handles per chunk
 int enumgen_block_threads(const famseq_model &m);
 // One-line description of the lane kernel's tiling (which members are looped / unrolled).

@@ -394,6 +394,7 @@ def test_packed_input_is_refused_to_a_kernel_that_rereads_fp64_rows(tmp_path, mo
     monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
     monkeypatch.setenv("FAMSEQ_KEEP_SRC", "1")
     monkeypatch.setenv("FAMSEQ_JIT_SOURCE_ONLY", "1")
+    monkeypatch.setenv("FAMSEQ_LANE_CAP", "6")  # the 6-member block: the form these pedigrees run in (the 7-member one spills)
     seen = set()
     for seed in (2, 8, 10):
         _, ped, mu = soak_pedigree(seed)
@@ -541,3 +542,20 @@ def test_compute_first_lane_shell_on_wider_pedigrees(case, tmp_path, monkeypatch
     assert np.array_equal(single[(case.status & 3) != 1], case.single[(case.status & 3) != 1])
     np.testing.assert_allclose(post[ok], case.post[ok], rtol=1e-12, atol=0)
     assert np.all(np.isnan(post[~ok]))
+
+
+@pytest.mark.parametrize("name", ["bn_synth:ped10", "bn_synth:ped10_x", "bn_vcf:fam01"])
+def test_six_member_block_form_of_wide_pedigrees(name, tmp_path, monkeypatch):
+    """Wide pedigrees are generated in two block sizes (kEnumVariants: a 7-member unrolled block first, the
+    6-member one behind it); the host tests above see the first, the GPU picks by register spill — at ten
+    members the 6-member form.  This keeps that form under the same fixtures without a GPU."""
+    monkeypatch.setenv("FAMSEQ_LANE_CAP", "6")
+    case = [c for c in CASES if c.name == name][0]
+    model = fs.make_model(case.pedigree(), **case.consts)
+    fn = build_host_kernel(model, "lane", tmp_path, monkeypatch)
+    assert "6 unrolled members" in open(tmp_path / "cache_lane" / "k.cpp").readline()
+    post, single, st = run_host(fn, model, case.lk, case.flags)
+    assert np.array_equal(st, case.status)
+    ok = (case.status & 3) == 0
+    assert np.array_equal(single[(case.status & 3) != 1], case.single[(case.status & 3) != 1])
+    np.testing.assert_allclose(post[ok], case.post[ok], rtol=1e-12, atol=0)
