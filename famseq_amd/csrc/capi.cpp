@@ -331,9 +331,19 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
   if (c->lane_failed) return false;
   try {
     const famseq_model &mdl = c->model;
-    const std::string src = elim ? jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants)
-                                 : jit_pick_variant([&mdl](int v) { return enumgen_source(mdl, v, 0, true); }, kEnumVariants, &c->lane_call_variant);
-    if (!elim) c->lane_reads_rows = enumgen_reads_global_rows(mdl, c->lane_call_variant) ? 1 : 0;
+    std::string src;
+    if (elim) {
+      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants);
+    } else {
+      // the same block size as the plain lane kernel runs with (variants 0-1 / 2-3: kEnumVariants), so that a batch
+      // gives the same bits whether it goes through the fused kernel or through the separate stages
+      if (!load_lane(c, 0)) return false;
+      const int base = c->lane_variant >= 0 ? (c->lane_variant & ~1) : 0;
+      int pick = 0;
+      src = jit_pick_variant([&mdl, base](int v) { return enumgen_source(mdl, base + v, 0, true); }, 2, &pick);
+      c->lane_call_variant = base + pick;
+      c->lane_reads_rows = enumgen_reads_global_rows(mdl, c->lane_call_variant) ? 1 : 0;
+    }
     if (c->device < 0) {
       k.path = jit_compile(src);
       return true;
@@ -542,7 +552,7 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
   c->json.pop_back();
   c->json += ",\"engine\":" + std::to_string(c->engine) + ",\"elim_supported\":" +
              std::string(elim_supported(c->model, nullptr) ? "1" : "0") + ",\"elim_code_object\":\"" + json_str(c->elim.path) +
-             "\",\"enum_lane_shape\":\"" + enumgen_describe(c->model) + "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + json_str(c->lane.path) +
+             "\",\"enum_lane_shape\":\"" + enumgen_describe(c->model, c->lane_variant) + "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + json_str(c->lane.path) +
              "\",\"enum_lane_failed\":" + std::string(c->lane_failed ? "1" : "0") + ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
              ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + ",\"elim_variant\":" + std::to_string(c->elim_variant) +
              ",\"elim_conditioned_members\":" + std::to_string(elim_conditioned_members(c->model)) +

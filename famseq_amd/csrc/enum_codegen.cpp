@@ -671,8 +671,8 @@ class Gen {
 
 }  // namespace
 
-std::string enumgen_describe(const famseq_model &m) {
-  int cap = 6;
+std::string enumgen_describe(const famseq_model &m, int variant) {
+  int cap = (variant >= 0 && variant < 2) ? 7 : 6;  // kEnumVariants; unknown yet (-1): the 6-member form
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);
   const Shape s = choose_shape(m, cap);
   std::string d = "looped members [";

@@ -27,7 +27,7 @@ bool enumgen_reads_global_rows(const famseq_model &m, int variant);
 int enumgen_sites_per_chunk(const famseq_model &m, int group_digits);  // sites a workgroup handles per chunk
 int enumgen_block_threads(const famseq_model &m);
 // One-line description of the lane kernel's tiling (which members are looped / unrolled).
-std::string enumgen_describe(const famseq_model &m);
+std::string enumgen_describe(const famseq_model &m, int variant = -1);  // shape of the one-lane-per-site kernel of that variant
 
 }  // namespace famseq
 #endif
