@@ -553,7 +553,7 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
   c->json += ",\"engine\":" + std::to_string(c->engine) + ",\"elim_supported\":" +
              std::string(elim_supported(c->model, nullptr) ? "1" : "0") + ",\"elim_code_object\":\"" + json_str(c->elim.path) +
              "\",\"enum_lane_shape\":\"" + enumgen_describe(c->model, c->lane_variant) + "\",\"enum_impl\":" + std::to_string(c->enum_impl) + ",\"enum_lane_code_object\":\"" + json_str(c->lane.path) +
-             "\",\"enum_lane_failed\":" + std::string(c->lane_failed ? "1" : "0") + ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
+             "\",\"enum_lane_failed\":" + std::string(c->lane_failed ? "1" : "0") + ",\"enum_lane_error\":\"" + json_str(c->lane_error.substr(0, 400)) + "\"" + ",\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) +
              ",\"blocks_per_cu\":" + std::to_string(c->blocks_per_cu) + ",\"elim_variant\":" + std::to_string(c->elim_variant) +
              ",\"elim_conditioned_members\":" + std::to_string(elim_conditioned_members(c->model)) +
              ",\"elim_blocks_per_cu\":" + std::to_string(c->elim_blocks_per_cu) + ",\"enum_lane_variant\":" +
