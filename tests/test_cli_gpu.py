@@ -227,3 +227,32 @@ def test_binary_result_file_unpacks_to_the_same_text(vcf, ped, tmp_path):
     # and the Python reader sees the same numbers
     res = plfile.read_results(str(po))
     assert res["status"].shape[0] == sum(1 for line in open(txt) if not line.startswith("#"))
+
+
+def test_packed_pipeline_edge_sizes(tmp_path):
+    """`FamSeq PL` (reader / GPU / writer threads over three rotating batches): an empty packed file, fewer
+    sites than one batch, exactly three batches and a ragged fourth — text and packed output alike; the packed
+    results unpack to the text."""
+    import numpy as np
+
+    from famseq_amd import pedigree, synth
+
+    ped = pedigree.synthetic_pedigree("ped5")
+    mo, fa = ped.relations()
+    pedf = tmp_path / "p.ped"
+    pedigree.write_ped(ped, str(pedf))
+    for n, batch in ((0, "4"), (3, "4"), (12, "4"), (14, "4"), (700, "256")):
+        pl, known, _ = synth.gen_sites(mo, fa, max(n, 1), synth.SEED_BASE + 1)
+        fspl, txt, po, back = tmp_path / ("s%d.fspl" % n), tmp_path / ("t%d.txt" % n), tmp_path / ("r%d.fspo" % n), tmp_path / ("u%d.txt" % n)
+        plfile.write_plfile(str(fspl), ped.names, known[:n].astype(np.uint8), pl[:n].astype(np.uint16))
+        env = dict(os.environ, FAMSEQ_BATCH=batch)
+        for args, out in ((["PL", "-plFile", str(fspl), "-pedFile", str(pedf)], txt),
+                          (["PL", "-plFile", str(fspl), "-pedFile", str(pedf), "-binOutput"], po),
+                          (["unpack", "-plFile", str(fspl), "-poFile", str(po), "-pedFile", str(pedf)], back)):
+            p = subprocess.run([CLI] + args + ["-output", str(out)], capture_output=True, text=True, timeout=300, env=env)
+            assert p.returncode == 0, (n, args, p.stdout + p.stderr)
+        lines = [l for l in open(txt) if not l.startswith("#")]
+        assert len(lines) == n
+        assert open(back).read() == open(txt).read()
+        res = plfile.read_results(str(po))
+        assert res["status"].shape[0] == n
