@@ -383,8 +383,11 @@ struct Record {
   vector<Sample> samples;  // sequenced samples, in output column order
 };
 
+double now_s();
+
 class BatchCaller {
  public:
+  double t_gpu = 0, t_format = 0, t_write = 0;  // FAMSEQ_TIMING: where a flush spends its time
   BatchCaller(famseq_ctx *ctx, int n_members, const vector<int> &seq_members, std::ostream &out, size_t cap)
       : ctx_(ctx), n_(n_members), seq_(seq_members.begin(), seq_members.end()), out_(out), cap_(cap) {}
 
@@ -413,6 +416,7 @@ class BatchCaller {
     fpp_.resize(size_t(s) * k * 3);
     fgt_.resize(size_t(s) * k);
     status_.resize(flags_.size());
+    const double t0 = now_s();
     if (s > 0) {
       const bool packed = packed_ok_ && !pl_.empty();
       const int rc = famseq_bn_call_batch(ctx_, s, packed ? nullptr : lk_.data(), packed ? pl_.data() : nullptr,
@@ -423,6 +427,8 @@ class BatchCaller {
         return false;
       }
     }
+    const double t1 = now_s();
+    t_gpu += t1 - t0;
     vector<string> lines(q_.size());
     parallel_for(q_.size(), [&](size_t i) {
       const Record &r = q_[i];
@@ -464,11 +470,14 @@ class BatchCaller {
       }
       line += '\n';
     });
+    const double t2 = now_s();
+    t_format += t2 - t1;
     for (size_t i = 0; i < q_.size(); ++i) {
       if (q_[i].site >= 0 && (status_[q_[i].site] & 3))
         std::cout << "Warning: this variant hasn't been calculated: " << std::endl << q_[i].raw << std::endl;
       out_.write(lines[i].data(), (std::streamsize)lines[i].size());
     }
+    t_write += now_s() - t2;
     q_.clear();
     lk_.clear();
     pl_.clear();
@@ -1229,9 +1238,12 @@ bool run_vcf(const Options &o, const Ped &ped) {
     parallel_for(b.lines.size(), [&](size_t i) { parse_line(b.lines[i], b.parsed[i]); });
   };
   int cur = 0;
+  double t_load = 0, t_apply = 0, t_wait = 0;
+  const double t_begin = now_s();
   load(blocks[cur]);
   while (!blocks[cur].lines.empty() && ok) {
-    std::thread ahead([&, cur] { load(blocks[1 - cur]); });
+    std::thread ahead([&, cur] { const double t0 = now_s(); load(blocks[1 - cur]); t_load += now_s() - t0; });
+    const double ta = now_s();
     Block &b = blocks[cur];
     for (size_t i = 0; i < b.lines.size() && ok; ++i) {
       Parsed &q = b.parsed[i];
@@ -1246,9 +1258,16 @@ bool run_vcf(const Options &o, const Ped &ped) {
         }
       }
     }
+    const double tj = now_s();
+    t_apply += tj - ta;
     ahead.join();
+    t_wait += now_s() - tj;
     cur = 1 - cur;
   }
+  if (std::getenv("FAMSEQ_TIMING") && !o.pack_mode)
+    std::cerr << "FamSeq vcf: loop " << now_s() - t_begin << " s; reader thread (read + parse) busy " << t_load
+              << "; this thread: queueing + flushes " << t_apply << " (GPU calls " << caller.t_gpu << ", formatting " << caller.t_format
+              << ", writing " << caller.t_write << "), waiting for the reader " << t_wait << std::endl;
   if (o.pack_mode) {
     std::cout << packer.n_sites << " sites packed";
     if (packer.skipped) std::cout << ", " << packer.skipped << " skipped (PL/GL field is not a plain integer)";
