@@ -385,42 +385,101 @@ struct Record {
 
 double now_s();
 
+// n items in at most `parts` contiguous ranges, one thread each: f(lo, hi, part).  Returns the number of parts.
+template <class F>
+int parallel_ranges(size_t n, F f) {
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char *e = std::getenv("FAMSEQ_THREADS")) t = (unsigned)std::atoi(e);
+  t = std::max(1u, std::min(t, 32u));
+  if (n < 2048) t = 1;
+  vector<std::thread> pool;
+  for (unsigned k = 1; k < t; ++k) pool.emplace_back([=] { f(n * k / t, n * (k + 1) / t, (int)k); });
+  f(0, n / t, 0);
+  for (std::thread &th : pool) th.join();
+  return (int)t;
+}
+
+// Queue of output records between the drivers' line loops and the GPU.  Records (pass-through lines and
+// sites) are kept in input order; a full batch is handed to a flusher thread — GPU call
+// (famseq_bn_call_batch: posterior, Phred scaling and genotype call all on the device), formatting on all
+// cores, one write per formatting thread — while the driver's thread goes on filling the next batch.
+// (Round 1 did all of it on the driver's thread: of 1.14 s per 1 M ten-member VCF lines it spent 0.07 s in
+// GPU calls, 0.28 s formatting, 0.33 s in one ofstream::write per line and 0.43 s queueing.)
 class BatchCaller {
  public:
-  double t_gpu = 0, t_format = 0, t_write = 0;  // FAMSEQ_TIMING: where a flush spends its time
+  double t_gpu = 0, t_format = 0, t_write = 0, t_stall = 0;  // FAMSEQ_TIMING: where the flusher spends its time; driver waiting for it
   BatchCaller(famseq_ctx *ctx, int n_members, const vector<int> &seq_members, std::ostream &out, size_t cap)
       : ctx_(ctx), n_(n_members), seq_(seq_members.begin(), seq_members.end()), out_(out), cap_(cap) {}
+  ~BatchCaller() { wait(); }
 
   void literal(string line) {
     Record r;
     r.text = std::move(line);
-    q_.push_back(std::move(r));
+    cur_.q.push_back(std::move(r));
   }
   // lk: N x 3 in PED order; pl: n_seq x 3 packed integer PLs in column order, or NULL when some
   // field of the site is not a plain integer (the batch then goes through the fp64 input)
   bool site(Record &&r, const vector<double> &lk, const uint16_t *pl, uint8_t flags) {
-    r.site = (long)flags_.size();
-    lk_.insert(lk_.end(), lk.begin(), lk.end());
-    if (pl && packed_ok_) pl_.insert(pl_.end(), pl, pl + 3 * seq_.size());
-    else packed_ok_ = false;
-    flags_.push_back(flags);
-    q_.push_back(std::move(r));
-    return flags_.size() < cap_ || flush();
+    r.site = (long)cur_.flags.size();
+    cur_.lk.insert(cur_.lk.end(), lk.begin(), lk.end());
+    if (pl && cur_.packed_ok) cur_.pl.insert(cur_.pl.end(), pl, pl + 3 * seq_.size());
+    else cur_.packed_ok = false;
+    cur_.flags.push_back(flags);
+    cur_.q.push_back(std::move(r));
+    return cur_.flags.size() < cap_ || submit();
   }
-  // Posterior, Phred scaling and genotype call all happen on the device (famseq_bn_call_batch);
-  // what comes back per sequenced sample is exactly what gets printed.
+  // Everything queued so far is computed and written when this returns.
   bool flush() {
-    const int64_t s = (int64_t)flags_.size();
+    const bool ok = submit();
+    wait();
+    return ok && ok_;
+  }
+
+ private:
+  struct Batch {
+    vector<Record> q;
+    vector<double> lk;
+    vector<uint16_t> pl;
+    vector<uint8_t> flags;
+    bool packed_ok = true;
+    void clear() {
+      q.clear();
+      lk.clear();
+      pl.clear();
+      flags.clear();
+      packed_ok = true;
+    }
+  };
+
+  void wait() {
+    if (worker_.joinable()) {
+      const double t0 = now_s();
+      worker_.join();
+      t_stall += now_s() - t0;
+    }
+  }
+  // hand the current batch to the flusher (after the previous one is through) and start a fresh one
+  bool submit() {
+    wait();
+    if (!ok_) return false;
+    std::swap(cur_, fly_);
+    cur_.clear();
+    worker_ = std::thread([this] { ok_ = write_out(fly_); });
+    return true;
+  }
+
+  bool write_out(Batch &b) {
+    const int64_t s = (int64_t)b.flags.size();
     const size_t k = seq_.size();
     gpp_.resize(size_t(s) * k * 3);
     fpp_.resize(size_t(s) * k * 3);
     fgt_.resize(size_t(s) * k);
-    status_.resize(flags_.size());
+    status_.resize(b.flags.size());
     const double t0 = now_s();
     if (s > 0) {
-      const bool packed = packed_ok_ && !pl_.empty();
-      const int rc = famseq_bn_call_batch(ctx_, s, packed ? nullptr : lk_.data(), packed ? pl_.data() : nullptr,
-                                          flags_.data(), seq_.data(), (int32_t)k, gpp_.data(), fpp_.data(), fgt_.data(),
+      const bool packed = b.packed_ok && !b.pl.empty();
+      const int rc = famseq_bn_call_batch(ctx_, s, packed ? nullptr : b.lk.data(), packed ? b.pl.data() : nullptr,
+                                          b.flags.data(), seq_.data(), (int32_t)k, gpp_.data(), fpp_.data(), fgt_.data(),
                                           status_.data());
       if (rc != 0) {
         std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx_) << std::endl;
@@ -429,75 +488,72 @@ class BatchCaller {
     }
     const double t1 = now_s();
     t_gpu += t1 - t0;
-    vector<string> lines(q_.size());
-    parallel_for(q_.size(), [&](size_t i) {
-      const Record &r = q_[i];
-      string &line = lines[i];
-      if (r.site < 0) {
-        line.assign(r.text);
-      } else {
-        if (r.head) {
-          line.assign(r.head);
+    // every formatting thread appends its contiguous range of records to one string: T writes per batch
+    vector<string> text(64);
+    const int parts = parallel_ranges(b.q.size(), [&](size_t lo, size_t hi, int part) {
+      string &line = text[part];
+      line.reserve((hi - lo) * (64 + 56 * k));
+      for (size_t i = lo; i < hi; ++i) {
+        const Record &r = b.q[i];
+        if (r.site < 0) {
+          line += r.text;
         } else {
-          line.assign(r.raw, 0, r.prefix_len);  // columns 1-8 + FORMAT
-          line += ":GPP:FPP:FGT\t";
-        }
-        if (status_[r.site] & 3) {  // file.cpp:607-620
-          for (const Record::Sample &sm : r.samples) {
-            line.append(r.raw, sm.off, sm.len);
-            line += ":NA:NA:NA\t";
+          if (r.head) {
+            line += r.head;
+          } else {
+            line.append(r.raw, 0, r.prefix_len);  // columns 1-8 + FORMAT
+            line += ":GPP:FPP:FGT\t";
           }
-        } else {
-          for (size_t j = 0; j < k; ++j) {
-            const double *g = &gpp_[(size_t(r.site) * k + j) * 3], *f = &fpp_[(size_t(r.site) * k + j) * 3];
-            const int gt = fgt_[size_t(r.site) * k + j];
-            const Record::Sample &sm = r.samples[j];
-            if (sm.missing) {
-              for (uint32_t q = 0; q < r.n_fmt; ++q) line += "NA:";
-            } else {
+          if (status_[r.site] & 3) {  // file.cpp:607-620
+            for (const Record::Sample &sm : r.samples) {
               line.append(r.raw, sm.off, sm.len);
-              line += ':';
+              line += ":NA:NA:NA\t";
             }
-            put_double(line, g[0]); line += ',';
-            put_double(line, g[1]); line += ',';
-            put_double(line, g[2]); line += ':';
-            put_double(line, f[0]); line += ',';
-            put_double(line, f[1]); line += ',';
-            put_double(line, f[2]); line += ':';
-            line += gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t");
+          } else {
+            for (size_t j = 0; j < k; ++j) {
+              const double *g = &gpp_[(size_t(r.site) * k + j) * 3], *f = &fpp_[(size_t(r.site) * k + j) * 3];
+              const int gt = fgt_[size_t(r.site) * k + j];
+              const Record::Sample &sm = r.samples[j];
+              if (sm.missing) {
+                for (uint32_t q = 0; q < r.n_fmt; ++q) line += "NA:";
+              } else {
+                line.append(r.raw, sm.off, sm.len);
+                line += ':';
+              }
+              put_double(line, g[0]); line += ',';
+              put_double(line, g[1]); line += ',';
+              put_double(line, g[2]); line += ':';
+              put_double(line, f[0]); line += ',';
+              put_double(line, f[1]); line += ',';
+              put_double(line, f[2]); line += ':';
+              line += gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t");
+            }
           }
         }
+        line += '\n';
       }
-      line += '\n';
     });
     const double t2 = now_s();
     t_format += t2 - t1;
-    for (size_t i = 0; i < q_.size(); ++i) {
-      if (q_[i].site >= 0 && (status_[q_[i].site] & 3))
-        std::cout << "Warning: this variant hasn't been calculated: " << std::endl << q_[i].raw << std::endl;
-      out_.write(lines[i].data(), (std::streamsize)lines[i].size());
-    }
+    for (const Record &r : b.q)  // the reference's warning on stdout, in input order (file.cpp:607-612)
+      if (r.site >= 0 && (status_[r.site] & 3))
+        std::cout << "Warning: this variant hasn't been calculated: " << std::endl << r.raw << std::endl;
+    for (int part = 0; part < parts; ++part) out_.write(text[part].data(), (std::streamsize)text[part].size());
     t_write += now_s() - t2;
-    q_.clear();
-    lk_.clear();
-    pl_.clear();
-    flags_.clear();
-    packed_ok_ = true;
     return true;
   }
 
- private:
   famseq_ctx *ctx_;
   int n_;
   vector<int32_t> seq_;  // PED index of each sequenced output column, in input column order
   std::ostream &out_;
   size_t cap_;
-  vector<Record> q_;
-  vector<double> lk_, gpp_, fpp_;
-  vector<uint16_t> pl_;
+  Batch cur_, fly_;  // being filled by the driver / being written out by the flusher
+  std::thread worker_;
+  bool ok_ = true;
+  vector<double> gpp_, fpp_;
   vector<int8_t> fgt_;
-  vector<uint8_t> flags_, status_;
-  bool packed_ok_ = true;
+  vector<uint8_t> status_;
 };
 
 size_t batch_capacity() {
@@ -1266,8 +1322,9 @@ bool run_vcf(const Options &o, const Ped &ped) {
   }
   if (std::getenv("FAMSEQ_TIMING") && !o.pack_mode)
     std::cerr << "FamSeq vcf: loop " << now_s() - t_begin << " s; reader thread (read + parse) busy " << t_load
-              << "; this thread: queueing + flushes " << t_apply << " (GPU calls " << caller.t_gpu << ", formatting " << caller.t_format
-              << ", writing " << caller.t_write << "), waiting for the reader " << t_wait << std::endl;
+              << "; this thread: queueing " << t_apply << " of which waiting for the flusher " << caller.t_stall
+              << "; flusher thread: GPU calls " << caller.t_gpu << ", formatting " << caller.t_format << ", writing " << caller.t_write
+              << "; waiting for the reader " << t_wait << std::endl;
   if (o.pack_mode) {
     std::cout << packer.n_sites << " sites packed";
     if (packer.skipped) std::cout << ", " << packer.skipped << " skipped (PL/GL field is not a plain integer)";
