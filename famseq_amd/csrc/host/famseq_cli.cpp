@@ -18,6 +18,7 @@
 // queued and evaluated in batches on the GPU (famseq_bn_batch) with the output order preserved,
 // and only -method 1 exists here (methods 2/3 are other algorithms, out of scope).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,7 @@
 #include <unistd.h>
 
 #include "famseq_hip.h"
+#include "fmt_g6.h"
 
 namespace {
 
@@ -74,17 +76,37 @@ void split_views(std::string_view s, char sep, vector<std::string_view> &out) {
   out.push_back(s.substr(head));
 }
 
-// default ostream formatting of a double (precision 6, general)
-void put_double(string &out, double v) {
-  char buf[40];
-  if (std::isfinite(v)) {  // std::to_chars(general, 6) is printf's %g, exactly, at a third of the cost
-    const std::to_chars_result r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::general, 6);
-    out.append(buf, size_t(r.ptr - buf));
-    return;
+// Output text of one formatting thread: appended through a raw pointer (no per-piece capacity checks beyond room()),
+// kept from batch to batch.  Numbers go through famseq_fmt::g6 — printf's %g exactly, a third of to_chars' cost.
+struct TextBuf {
+  vector<char> v;
+  size_t n = 0;
+  char *room(size_t need) {
+    if (v.size() < n + need) v.resize(std::max(v.size() * 2, n + need + (size_t(1) << 16)));
+    return v.data() + n;
   }
-  std::snprintf(buf, sizeof buf, "%g", v);
-  out += buf;
-}
+  void put(const char *s, size_t len) {
+    std::memcpy(room(len), s, len);
+    n += len;
+  }
+  void put(std::string_view s) { put(s.data(), s.size()); }
+  void ch(char c) { *room(1) = c, ++n; }
+  void num(double x) {
+    char *p = room(32);
+    n += size_t(famseq_fmt::g6(p, x) - p);
+  }
+  // "a,b,c:d,e,f:" — the GPP and FPP triples of one sample
+  void triples(const double *g, const double *f) {
+    char *p = room(6 * 32 + 8), *q = p;
+    q = famseq_fmt::g6(q, g[0]), *q++ = ',';
+    q = famseq_fmt::g6(q, g[1]), *q++ = ',';
+    q = famseq_fmt::g6(q, g[2]), *q++ = ':';
+    q = famseq_fmt::g6(q, f[0]), *q++ = ',';
+    q = famseq_fmt::g6(q, f[1]), *q++ = ',';
+    q = famseq_fmt::g6(q, f[2]), *q++ = ':';
+    n += size_t(q - p);
+  }
+};
 
 // pow(10, -|x|/10) for a PL/GL field (file.cpp:588-590).  Integer fields (the usual PL) go
 // through a table filled with the same libm pow call, so the value is identical.
@@ -93,6 +115,8 @@ struct PlTable {
   PlTable() : lut(4096) {
     for (size_t k = 0; k < lut.size(); ++k) lut[k] = std::pow(10.0, -std::fabs(double(k)) / 10.0);
   }
+  // the likelihood of a packed integer PL: what operator() returned when it packed it
+  double value(uint16_t v) const { return v < lut.size() ? lut[v] : std::pow(10.0, -std::fabs(double(v)) / 10.0); }
   // *packed receives the integer PL (clamped to 65534: anything >= 3240 is exactly 0 anyway) or
   // is left untouched and *integral cleared when the field is not a plain non-negative integer.
   double operator()(const char *b, const char *e, uint16_t *packed, bool *integral) const {
@@ -488,49 +512,43 @@ class BatchCaller {
     }
     const double t1 = now_s();
     t_gpu += t1 - t0;
-    // every formatting thread appends its contiguous range of records to one string: T writes per batch
-    vector<string> text(64);
+    // every formatting thread appends its contiguous range of records to one buffer: T writes per batch
+    if (text_.size() < 64) text_.resize(64);
     const int parts = parallel_ranges(b.q.size(), [&](size_t lo, size_t hi, int part) {
-      string &line = text[part];
-      line.reserve((hi - lo) * (64 + 56 * k));
+      TextBuf &line = text_[part];
+      line.n = 0;
       for (size_t i = lo; i < hi; ++i) {
         const Record &r = b.q[i];
         if (r.site < 0) {
-          line += r.text;
+          line.put(r.text);
         } else {
           if (r.head) {
-            line += r.head;
+            line.put(r.head, std::strlen(r.head));
           } else {
-            line.append(r.raw, 0, r.prefix_len);  // columns 1-8 + FORMAT
-            line += ":GPP:FPP:FGT\t";
+            line.put(r.raw.data(), r.prefix_len);  // columns 1-8 + FORMAT
+            line.put(":GPP:FPP:FGT\t", 13);
           }
           if (status_[r.site] & 3) {  // file.cpp:607-620
             for (const Record::Sample &sm : r.samples) {
-              line.append(r.raw, sm.off, sm.len);
-              line += ":NA:NA:NA\t";
+              line.put(r.raw.data() + sm.off, sm.len);
+              line.put(":NA:NA:NA\t", 10);
             }
           } else {
             for (size_t j = 0; j < k; ++j) {
-              const double *g = &gpp_[(size_t(r.site) * k + j) * 3], *f = &fpp_[(size_t(r.site) * k + j) * 3];
               const int gt = fgt_[size_t(r.site) * k + j];
               const Record::Sample &sm = r.samples[j];
               if (sm.missing) {
-                for (uint32_t q = 0; q < r.n_fmt; ++q) line += "NA:";
+                for (uint32_t q = 0; q < r.n_fmt; ++q) line.put("NA:", 3);
               } else {
-                line.append(r.raw, sm.off, sm.len);
-                line += ':';
+                line.put(r.raw.data() + sm.off, sm.len);
+                line.ch(':');
               }
-              put_double(line, g[0]); line += ',';
-              put_double(line, g[1]); line += ',';
-              put_double(line, g[2]); line += ':';
-              put_double(line, f[0]); line += ',';
-              put_double(line, f[1]); line += ',';
-              put_double(line, f[2]); line += ':';
-              line += gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t");
+              line.triples(&gpp_[(size_t(r.site) * k + j) * 3], &fpp_[(size_t(r.site) * k + j) * 3]);
+              line.put(gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t"), 4);
             }
           }
         }
-        line += '\n';
+        line.ch('\n');
       }
     });
     const double t2 = now_s();
@@ -538,7 +556,7 @@ class BatchCaller {
     for (const Record &r : b.q)  // the reference's warning on stdout, in input order (file.cpp:607-612)
       if (r.site >= 0 && (status_[r.site] & 3))
         std::cout << "Warning: this variant hasn't been calculated: " << std::endl << r.raw << std::endl;
-    for (int part = 0; part < parts; ++part) out_.write(text[part].data(), (std::streamsize)text[part].size());
+    for (int part = 0; part < parts; ++part) out_.write(text_[part].v.data(), (std::streamsize)text_[part].n);
     t_write += now_s() - t2;
     return true;
   }
@@ -554,6 +572,7 @@ class BatchCaller {
   vector<double> gpp_, fpp_;
   vector<int8_t> fgt_;
   vector<uint8_t> status_;
+  vector<TextBuf> text_;
 };
 
 size_t batch_capacity() {
@@ -840,36 +859,40 @@ bool run_pl(const Options &o, const Ped &ped) {
     fout << std::endl;
   }
 
-  // Text of one batch (what `FamSeq PL` prints per site), formatted on all cores.
-  auto format_lines = [&](size_t n, const uint16_t *pl, const uint8_t *status, const double *gpp, const double *fpp, const int8_t *fgt,
-                          vector<string> &lines) {
-    lines.resize(n);
-    parallel_for(n, [&](size_t s) {
-      string &line = lines[s];
-      line.assign("PL:GPP:FPP:FGT\t");
-      for (size_t j = 0; j < k; j++) {
-        const uint16_t *p = &pl[(s * k + j) * 3];
-        char buf[48];
-        if (p[0] == 0xFFFF && p[1] == 0xFFFF && p[2] == 0xFFFF) std::snprintf(buf, sizeof buf, "NA");
-        else std::snprintf(buf, sizeof buf, "%u,%u,%u", p[0], p[1], p[2]);
-        line += buf;
-        if (status[s] & 3) {
-          line += ":NA:NA:NA\t";
-          continue;
+  // Text of one batch (what `FamSeq PL` prints per site), formatted on all cores: one buffer per thread, written in order.
+  vector<TextBuf> text(64);
+  auto put_uint = [](TextBuf &t, unsigned v) {
+    char *p = t.room(8);
+    t.n += size_t(std::to_chars(p, p + 8, v).ptr - p);
+  };
+  auto format_and_write = [&](size_t n, const uint16_t *pl, const uint8_t *status, const double *gpp, const double *fpp, const int8_t *fgt) {
+    const int parts = parallel_ranges(n, [&](size_t lo, size_t hi, int part) {
+      TextBuf &line = text[part];
+      line.n = 0;
+      for (size_t s = lo; s < hi; ++s) {
+        line.put("PL:GPP:FPP:FGT\t", 15);
+        for (size_t j = 0; j < k; j++) {
+          const uint16_t *p = &pl[(s * k + j) * 3];
+          if (p[0] == 0xFFFF && p[1] == 0xFFFF && p[2] == 0xFFFF) {
+            line.put("NA", 2);
+          } else {
+            put_uint(line, p[0]), line.ch(',');
+            put_uint(line, p[1]), line.ch(',');
+            put_uint(line, p[2]);
+          }
+          if (status[s] & 3) {
+            line.put(":NA:NA:NA\t", 10);
+            continue;
+          }
+          line.ch(':');
+          line.triples(&gpp[(s * k + j) * 3], &fpp[(s * k + j) * 3]);
+          const int gt = fgt[s * k + j];
+          line.put(gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t"), 4);
         }
-        const double *g = &gpp[(s * k + j) * 3], *f = &fpp[(s * k + j) * 3];
-        line += ':';
-        put_double(line, g[0]); line += ',';
-        put_double(line, g[1]); line += ',';
-        put_double(line, g[2]); line += ':';
-        put_double(line, f[0]); line += ',';
-        put_double(line, f[1]); line += ',';
-        put_double(line, f[2]); line += ':';
-        const int gt = fgt[s * k + j];
-        line += gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t");
+        line.ch('\n');
       }
-      line += '\n';
     });
+    for (int part = 0; part < parts; ++part) fout.write(text[part].v.data(), (std::streamsize)text[part].n);
   };
 
   if (!o.unpack_mode) {
@@ -940,7 +963,6 @@ bool run_pl(const Options &o, const Ped &ped) {
       if (ofd < 0) write_ok = false;
     }
     std::thread writer([&] {
-      vector<string> lines;
       for (;;) {
         const int i = to_writer.take();
         if (i < 0) break;
@@ -957,8 +979,7 @@ bool run_pl(const Options &o, const Ped &ped) {
           write_ok = g;
           written += b.n;
         } else {
-          format_lines(b.n, b.pl, b.status, b.gpp, b.fpp, b.fgt, lines);
-          for (size_t s = 0; s < b.n; s++) fout.write(lines[s].data(), (std::streamsize)lines[s].size());
+          format_and_write(b.n, b.pl, b.status, b.gpp, b.fpp, b.fgt);
           write_ok = write_ok && !fout.fail();
         }
         t_write += now_s() - t0;
@@ -1009,7 +1030,6 @@ bool run_pl(const Options &o, const Ped &ped) {
   vector<uint16_t> pl(cap * k * 3);
   vector<double> gpp(cap * k * 3), fpp(cap * k * 3);
   vector<int8_t> fgt(cap * k);
-  vector<string> lines;
   bool ok = true;
   while (ok) {
     uint64_t bn = 0;
@@ -1035,8 +1055,7 @@ bool run_pl(const Options &o, const Ped &ped) {
       const char *r = raw.data() + s * rec;
       for (size_t j = 0; j < k; j++) std::memcpy(&pl[(s * k + j) * 3], r + 1 + 6 * seq_cols[j], 6);
     });
-    format_lines(n, pl.data(), status.data(), gpp.data(), fpp.data(), fgt.data(), lines);
-    for (size_t s = 0; s < n; s++) fout.write(lines[s].data(), (std::streamsize)lines[s].size());
+    format_and_write(n, pl.data(), status.data(), gpp.data(), fpp.data(), fgt.data());
   }
   fout.close();
   return ok && !fout.fail();
@@ -1051,9 +1070,59 @@ int chrom_number(const string &c) {  // file.cpp:321-343
   return std::atoi(c.compare(0, 3, "chr") == 0 ? c.c_str() + 3 : c.c_str());
 }
 
+// The input as std::getline would cut it — lines up to the next '\n', a last line without one counts — over the
+// memory-mapped file: no copy per line, and what the output echoes of a line (columns 1-9, the sample fields) is
+// pointed at in place until the batch is written.  What cannot be mapped (a pipe) is read whole.
+struct LineSource {
+  const char *cur = nullptr, *end = nullptr;
+  void *map = nullptr;
+  size_t map_len = 0;
+  string owned;
+  bool open(const string &path) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      void *mp = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (mp != MAP_FAILED) {
+        ::madvise(mp, (size_t)st.st_size, MADV_SEQUENTIAL);
+        map = mp, map_len = (size_t)st.st_size;
+        cur = static_cast<const char *>(mp), end = cur + map_len;
+        ::close(fd);
+        return true;
+      }
+    }
+    char buf[1 << 16];
+    ssize_t r;
+    while ((r = ::read(fd, buf, sizeof buf)) > 0) owned.append(buf, size_t(r));
+    ::close(fd);
+    cur = owned.data(), end = cur + owned.size();
+    return true;
+  }
+  bool next(std::string_view &line) {
+    if (cur >= end) return false;
+    const char *nl = static_cast<const char *>(std::memchr(cur, '\n', size_t(end - cur)));
+    line = std::string_view(cur, size_t((nl ? nl : end) - cur));
+    cur = nl ? nl + 1 : end;
+    return true;
+  }
+  ~LineSource() {
+    if (map) ::munmap(map, map_len);
+  }
+};
+
+// run `f(t)` on threads 0..n-1 (the caller's thread takes 0)
+template <class F>
+void on_threads(int n, F f) {
+  vector<std::thread> pool;
+  for (int t = 1; t < n; ++t) pool.emplace_back([=] { f(t); });
+  f(0);
+  for (std::thread &th : pool) th.join();
+}
+
 bool run_vcf(const Options &o, const Ped &ped) {
-  std::ifstream fin(o.vcf_files[0].c_str());
-  if (!fin.is_open()) {
+  LineSource fin;
+  if (!fin.open(o.vcf_files[0])) {
     std::cout << "Cannot open " << o.vcf_files[0] << std::endl;
     return false;
   }
@@ -1090,22 +1159,24 @@ bool run_vcf(const Options &o, const Ped &ped) {
     fout << "##FS genotype frequency for chromosome X of male in population (Rare): "; put_triple(fout, m.genoProbXN); fout << std::endl;
     fout << "##FS genotype frequency for chromosome X of male in population (Common): "; put_triple(fout, m.genoProbXK); fout << std::endl;
   };
-  string title, line;
+  string title;
+  std::string_view line;
   bool need_tags = true, need_info = true, have_line = false;
-  while (std::getline(fin, line)) {
+  auto after_hashes = [](std::string_view l, size_t n) { return l.size() > 2 ? l.substr(2, n) : std::string_view(); };
+  while (fin.next(line)) {
     if (!line.empty() && line[0] == '#') {
       if (title.size() > 2) {
         fout << title << std::endl;
-        if (title.compare(2, 6, "FORMAT") == 0 && line.compare(2, 4, "INFO") == 0 && need_tags) {
+        if (title.compare(2, 6, "FORMAT") == 0 && after_hashes(line, 4) == "INFO" && need_tags) {
           format_tags(false);
           need_tags = false;
         }
-        if (line.compare(2, 6, "contig") == 0 && need_info) {
+        if (after_hashes(line, 6) == "contig" && need_info) {
           fs_info();
           need_info = false;
         }
       }
-      title = line;
+      title.assign(line);
       continue;
     }
     have_line = true;
@@ -1130,7 +1201,8 @@ bool run_vcf(const Options &o, const Ped &ped) {
         sequenced[j] = 1;
         break;
       }
-  vector<int> seq_cols, seq_members;
+  vector<int> seq_cols;
+  vector<int32_t> seq_members;
   for (size_t i = 0; i < ncol; i++)
     if (v2p[i] >= 0) {
       seq_cols.push_back((int)i);
@@ -1175,34 +1247,54 @@ bool run_vcf(const Options &o, const Ped &ped) {
     ctx = make_ctx(o, ped, sequenced, m);
     if (!ctx) return false;
   }
-  BatchCaller caller(ctx, ped.n(), seq_members, fout, batch_capacity());
   const PlTable pl;
-  const size_t n_seq = seq_cols.size();
-  bool ok = true;
+  const size_t n_seq = seq_cols.size(), N3 = size_t(3) * ped.n();
 
-  // One input line -> what to do with it.  Pure function of the line (no shared state), so a block
-  // of lines is parsed on all host cores and then applied in input order.
-  struct Parsed {
-    enum Kind { kDrop, kEcho, kSite } kind = kDrop;
-    string echo;  // kEcho: the "allLine" echo (9 columns + sequenced samples)
-    Record rec;   // kSite
-    vector<double> lk;
-    vector<uint16_t> pl16;
-    bool integral = true;
-    uint8_t flags = 0;
+  // What one parsing thread makes of its contiguous range of a block's lines, in input order.  The same thread
+  // formats the same range once the block's sites are back from the GPU.
+  struct Item {
+    const char *raw;       // site: the input line (mapped; columns 1-9 and the sample fields are printed from it)
+    uint32_t raw_len;
+    uint32_t prefix_len;   // site: columns 1-9 without the tab after FORMAT
+    uint32_t n_fmt;        // site: FORMAT keys (a missing sample prints that many "NA:")
+    int32_t site;          // index among this thread's sites; -1: an echoed line, text = echo[echo_off, +echo_len)
+    uint32_t echo_off, echo_len;
   };
-  auto parse_line = [&](string &line, Parsed &out) {
-    out.kind = Parsed::kDrop;
+  struct Part {
+    vector<Item> items;
+    vector<char> echo;
+    vector<uint16_t> pl;                 // [site][n_seq][3]; 0xFFFF x3 = the sample's row stays {1,1,1}
+    vector<uint8_t> flags;               // [site]
+    vector<Record::Sample> samples;      // [site][n_seq]
+    vector<uint32_t> explicit_sites;     // sites with a PL/GL field that is not a plain integer ...
+    vector<double> explicit_lk;          // ... and their N x 3 likelihoods (the batch then goes in as fp64)
+    size_t base = 0;                     // index of this thread's first site in the batch
+    bool any_failed = false;
+    void clear() {
+      items.clear(), echo.clear(), pl.clear(), flags.clear(), samples.clear(), explicit_sites.clear(), explicit_lk.clear();
+      any_failed = false;
+    }
+  };
+
+  // One input line -> an Item (or nothing).  Pure function of the line (no shared state).
+  auto parse_line = [&](std::string_view line, Part &out) {
     if (line[0] == '#') return;
     thread_local vector<std::string_view> t, fmt, sub;
+    thread_local vector<double> lkrow;
     split_views(line, '\t', t);
     if (t.size() < 9 + ncol) return;  // malformed line (the reference would read out of bounds)
     auto echo = [&] {
       if (o.pack_mode) return;
-      out.kind = Parsed::kEcho;
-      out.echo.clear();
-      for (int i = 0; i < 9; i++) (out.echo += t[i]) += '\t';
-      for (int c : seq_cols) (out.echo += t[9 + c]) += '\t';
+      const size_t at = out.echo.size();
+      for (int i = 0; i < 9; i++) {
+        out.echo.insert(out.echo.end(), t[i].begin(), t[i].end());
+        out.echo.push_back('\t');
+      }
+      for (int c : seq_cols) {
+        out.echo.insert(out.echo.end(), t[9 + c].begin(), t[9 + c].end());
+        out.echo.push_back('\t');
+      }
+      out.items.push_back(Item{nullptr, 0, 0, 0, -1, uint32_t(at), uint32_t(out.echo.size() - at)});
     };
     if (use_loc) {
       const int c = chrom_number(string(t[0]));
@@ -1227,7 +1319,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
       if (o.all_line) echo();
       return;
     }
-    out.flags = uint8_t((t[2] != "." ? FAMSEQ_FLAG_KNOWN : 0) | (is_x ? FAMSEQ_FLAG_CHRX : 0));
+    const uint8_t flags = uint8_t((t[2] != "." ? FAMSEQ_FLAG_KNOWN : 0) | (is_x ? FAMSEQ_FLAG_CHRX : 0));
     split_views(t[8], ':', fmt);
     size_t n_miss = 0;
     for (int c : seq_cols) n_miss += t[9 + c].size() < 5;
@@ -1242,20 +1334,20 @@ bool run_vcf(const Options &o, const Ped &ped) {
       echo();
       return;
     }
-    out.kind = Parsed::kSite;
-    Record &r = out.rec;
-    r = Record();
     const char *base = line.data();
-    r.prefix_len = uint32_t(t[8].data() + t[8].size() - base);
-    r.n_fmt = uint32_t(fmt.size());
-    out.lk.assign(size_t(3) * ped.n(), 1.0);
-    out.pl16.assign(3 * n_seq, uint16_t(0xFFFF));  // 0xFFFF x3 = missing sample
-    out.integral = true;
+    const size_t site = out.flags.size();
+    out.items.push_back(Item{base, uint32_t(line.size()), uint32_t(t[8].data() + t[8].size() - base), uint32_t(fmt.size()),
+                             int32_t(site), 0, 0});
+    out.flags.push_back(flags);
+    out.pl.resize((site + 1) * 3 * n_seq, uint16_t(0xFFFF));  // 0xFFFF x3 = missing sample
+    uint16_t *pl16 = &out.pl[site * 3 * n_seq];
+    lkrow.assign(N3, 1.0);
+    bool integral = true;
     size_t col = 0;
     for (int c : seq_cols) {
       const size_t this_col = col++;
       const std::string_view f = t[9 + c];
-      r.samples.push_back({uint32_t(f.data() - base), uint32_t(f.size()), f.size() < 5});
+      out.samples.push_back({uint32_t(f.data() - base), uint32_t(f.size()), f.size() < 5});
       if (f.size() < 5) continue;  // missing sample: flat likelihood (file.cpp:927-933)
       split_views(f, ':', sub);
       if (sub.size() != fmt.size()) continue;  // row stays {1,1,1} (file.cpp:573-578)
@@ -1264,76 +1356,219 @@ bool run_vcf(const Options &o, const Ped &ped) {
       for (int g = 0; g < 3; g++) {
         const char *e = static_cast<const char *>(std::memchr(b, ',', size_t(end - b)));
         if (!e) e = end;
-        out.lk[size_t(3) * v2p[c] + g] = pl(b, e, &out.pl16[3 * this_col + g], &out.integral);
+        lkrow[size_t(3) * v2p[c] + g] = pl(b, e, &pl16[3 * this_col + g], &integral);
         b = e < end ? e + 1 : end;
       }
     }
-    r.raw = std::move(line);  // last: the views above point into it (a moved std::string keeps its buffer)
+    if (!integral) {
+      out.explicit_sites.push_back(uint32_t(site));
+      out.explicit_lk.insert(out.explicit_lk.end(), lkrow.begin(), lkrow.end());
+    }
   };
 
-  // Two blocks in rotation: while one is applied (GPU batch, formatting, output) the next is read
-  // and parsed by a helper thread.  Only the helper touches `fin` / `line`; only this thread
-  // touches the caller, the packer and the output.
+  // ---- the pipeline.  A block of input lines is ONE batch: this thread cuts it into lines and has it parsed on all
+  // cores (each thread its contiguous range, into its own Part), lays the parts' packed PLs end to end in a pinned
+  // buffer and hands the block to the flusher thread — GPU call (famseq_bn_call_batch: posterior, Phred scaling and
+  // genotype call on the device), formatting (each thread the range it parsed), one write per thread — while it goes on
+  // with the next block in the other slot.  (Before: lines copied one by one out of an ifstream, parsed results moved
+  // one by one into the batch by this thread, 0.94 of the loop's 1.0 s per 1 M ten-member sites.)
   const size_t block = std::min<size_t>(batch_capacity(), size_t(1) << 16);
-  struct Block {
-    vector<string> lines;
-    vector<Parsed> parsed;
-  } blocks[2];
+  unsigned n_threads = std::thread::hardware_concurrency();
+  if (const char *e = std::getenv("FAMSEQ_THREADS")) n_threads = (unsigned)std::atoi(e);
+  n_threads = std::max(1u, std::min(n_threads, 32u));
+  struct Slot {
+    vector<std::string_view> lines;
+    vector<Part> parts;
+    int n_parts = 0;
+    size_t n_sites = 0;
+    bool packed = true;
+    PlBatch io;          // pinned: pl + flags in, gpp / fpp / fgt / status out
+    vector<double> lk;   // fp64 input, only for a block with a non-integer PL/GL field
+    vector<TextBuf> text;
+  } slots[2];
+  bool ok = true;
+  for (Slot &sl : slots) sl.parts.resize(n_threads), sl.text.resize(n_threads);
+
+  double t_lines = 0, t_parse = 0, t_gather = 0, t_stall = 0, t_gpu = 0, t_format = 0, t_write = 0;
+  Channel to_flusher, to_driver;
+  std::atomic<bool> flush_ok{true};
+  std::thread flusher([&] {
+    for (;;) {
+      const int i = to_flusher.take();
+      if (i < 0) break;
+      Slot &sl = slots[i];
+      const size_t k = n_seq;
+      const double t0 = now_s();
+      if (sl.n_sites > 0 && flush_ok) {
+        const int rc = famseq_bn_call_batch(ctx, (int64_t)sl.n_sites, sl.packed ? nullptr : sl.lk.data(), sl.packed ? sl.io.pl : nullptr,
+                                            sl.io.flags, seq_members.data(), (int32_t)k, sl.io.gpp, sl.io.fpp, sl.io.fgt, sl.io.status);
+        if (rc != 0) {
+          std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx) << std::endl;
+          flush_ok = false;
+        }
+      }
+      const double t1 = now_s();
+      t_gpu += t1 - t0;
+      if (flush_ok) {
+        on_threads(sl.n_parts, [&](int t) {
+          Part &pt = sl.parts[t];
+          TextBuf &out = sl.text[t];
+          out.n = 0;
+          for (const Item &it : pt.items) {
+            if (it.site < 0) {
+              out.put(pt.echo.data() + it.echo_off, it.echo_len);
+            } else {
+              const size_t s = pt.base + size_t(it.site);
+              const Record::Sample *sm = &pt.samples[size_t(it.site) * k];
+              out.put(it.raw, it.prefix_len);  // columns 1-8 + FORMAT
+              out.put(":GPP:FPP:FGT\t", 13);
+              if (sl.io.status[s] & 3) {  // file.cpp:607-620
+                pt.any_failed = true;
+                for (size_t j = 0; j < k; ++j) {
+                  out.put(it.raw + sm[j].off, sm[j].len);
+                  out.put(":NA:NA:NA\t", 10);
+                }
+              } else {
+                for (size_t j = 0; j < k; ++j) {
+                  if (sm[j].missing) {
+                    for (uint32_t q = 0; q < it.n_fmt; ++q) out.put("NA:", 3);
+                  } else {
+                    out.put(it.raw + sm[j].off, sm[j].len);
+                    out.ch(':');
+                  }
+                  out.triples(&sl.io.gpp[(s * k + j) * 3], &sl.io.fpp[(s * k + j) * 3]);
+                  const int gt = sl.io.fgt[s * k + j];
+                  out.put(gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t"), 4);
+                }
+              }
+            }
+            out.ch('\n');
+          }
+        });
+        const double t2 = now_s();
+        t_format += t2 - t1;
+        for (int t = 0; t < sl.n_parts; ++t) {
+          const Part &pt = sl.parts[t];
+          if (pt.any_failed)  // the reference's warning on stdout, in input order (file.cpp:607-612)
+            for (const Item &it : pt.items)
+              if (it.site >= 0 && (sl.io.status[pt.base + size_t(it.site)] & 3))
+                std::cout << "Warning: this variant hasn't been calculated: " << std::endl << std::string_view(it.raw, it.raw_len) << std::endl;
+          fout.write(sl.text[t].v.data(), (std::streamsize)sl.text[t].n);
+        }
+        t_write += now_s() - t2;
+      }
+      to_driver.put(i);
+    }
+  });
+
+  const double t_begin = now_s();
+  to_driver.put(0), to_driver.put(1);
   bool more = have_line;
-  auto load = [&](Block &b) {
-    b.lines.clear();
-    while (more && b.lines.size() < block) {  // `line` holds the next unread line
-      if (line.size() < 2) {                  // the reference stops at the first empty line
+  while (more && ok && flush_ok) {
+    double t0 = now_s();
+    const int i = to_driver.take();  // a slot whose previous block is written
+    Slot &sl = slots[i];
+    double t1 = now_s();
+    t_stall += t1 - t0;
+    sl.lines.clear();
+    while (more && sl.lines.size() < block) {  // `line` holds the next unread line
+      if (line.size() < 2) {                   // the reference stops at the first empty line
         more = false;
         break;
       }
-      b.lines.push_back(std::move(line));
-      more = bool(std::getline(fin, line));
+      sl.lines.push_back(line);
+      more = fin.next(line);
     }
-    if (b.parsed.size() < b.lines.size()) b.parsed.resize(b.lines.size());
-    parallel_for(b.lines.size(), [&](size_t i) { parse_line(b.lines[i], b.parsed[i]); });
-  };
-  int cur = 0;
-  double t_load = 0, t_apply = 0, t_wait = 0;
-  const double t_begin = now_s();
-  load(blocks[cur]);
-  while (!blocks[cur].lines.empty() && ok) {
-    std::thread ahead([&, cur] { const double t0 = now_s(); load(blocks[1 - cur]); t_load += now_s() - t0; });
-    const double ta = now_s();
-    Block &b = blocks[cur];
-    for (size_t i = 0; i < b.lines.size() && ok; ++i) {
-      Parsed &q = b.parsed[i];
-      if (q.kind == Parsed::kEcho) {
-        caller.literal(std::move(q.echo));
-      } else if (q.kind == Parsed::kSite) {
-        if (o.pack_mode) {
-          if (q.integral) packer.add(q.flags, q.pl16.data());
-          else packer.skipped++;
-        } else {
-          ok = caller.site(std::move(q.rec), q.lk, q.integral ? q.pl16.data() : nullptr, q.flags);
+    const size_t nl = sl.lines.size();
+    if (nl == 0) {
+      to_driver.put(i);
+      break;
+    }
+    sl.n_parts = nl < 2048 ? 1 : (int)n_threads;
+    double t2 = now_s();
+    t_lines += t2 - t1;
+    on_threads(sl.n_parts, [&](int t) {
+      Part &pt = sl.parts[t];
+      pt.clear();
+      for (size_t q = nl * t / sl.n_parts, e = nl * (t + 1) / sl.n_parts; q < e; ++q) parse_line(sl.lines[q], pt);
+    });
+    double t3 = now_s();
+    t_parse += t3 - t2;
+    size_t total = 0;
+    bool packed = true;
+    for (int t = 0; t < sl.n_parts; ++t) {
+      sl.parts[t].base = total;
+      total += sl.parts[t].flags.size();
+      packed = packed && sl.parts[t].explicit_sites.empty();
+    }
+    sl.n_sites = total, sl.packed = packed;
+    if (o.pack_mode) {  // records of the integer sites, in input order; nothing goes to the GPU
+      for (int t = 0; t < sl.n_parts; ++t) {
+        const Part &pt = sl.parts[t];
+        size_t x = 0;
+        for (size_t q = 0; q < pt.flags.size(); ++q) {
+          if (x < pt.explicit_sites.size() && pt.explicit_sites[x] == q) {
+            ++x, packer.skipped++;
+            continue;
+          }
+          packer.add(pt.flags[q], &pt.pl[q * 3 * n_seq]);
         }
       }
+      t_gather += now_s() - t3;
+      to_driver.put(i);
+      continue;
     }
-    const double tj = now_s();
-    t_apply += tj - ta;
-    ahead.join();
-    t_wait += now_s() - tj;
-    cur = 1 - cur;
+    if (!packed) sl.lk.resize(total * N3);
+    if (sl.io.cap < total) {  // pinned, sized by the first block (a short file does not pay for 65,536 sites)
+      sl.io.release();
+      if (!sl.io.alloc(total, std::max<size_t>(n_seq, 1))) {
+        std::cerr << "cannot allocate pinned host buffers" << std::endl;
+        ok = false;
+        sl.io = PlBatch();
+        to_driver.put(i);
+        break;
+      }
+    }
+    on_threads(sl.n_parts, [&](int t) {  // the parts end to end: what the GPU call reads
+      const Part &pt = sl.parts[t];
+      const size_t n = pt.flags.size();
+      if (n == 0) return;
+      std::memcpy(sl.io.flags + pt.base, pt.flags.data(), n);
+      std::memcpy(sl.io.pl + pt.base * 3 * n_seq, pt.pl.data(), n * 6 * n_seq);
+      if (packed) return;
+      // fp64 rows: the table's value for every integer field (what the parser computed for it), the parsed rows of the others
+      double *rows = sl.lk.data() + pt.base * N3;
+      std::fill(rows, rows + n * N3, 1.0);
+      for (size_t q = 0; q < n; ++q)
+        for (size_t j = 0; j < n_seq; ++j) {
+          const uint16_t *p = &pt.pl[(q * n_seq + j) * 3];
+          if (p[0] == 0xFFFF && p[1] == 0xFFFF && p[2] == 0xFFFF) continue;
+          for (int g = 0; g < 3; ++g) rows[q * N3 + size_t(3) * seq_members[j] + g] = pl.value(p[g]);
+        }
+      for (size_t x = 0; x < pt.explicit_sites.size(); ++x)
+        std::copy(&pt.explicit_lk[x * N3], &pt.explicit_lk[(x + 1) * N3], rows + size_t(pt.explicit_sites[x]) * N3);
+    });
+    t_gather += now_s() - t3;
+    to_flusher.put(i);
   }
+  to_flusher.put(-1);
+  flusher.join();
+  ok = ok && flush_ok;
   if (std::getenv("FAMSEQ_TIMING") && !o.pack_mode)
-    std::cerr << "FamSeq vcf: loop " << now_s() - t_begin << " s; reader thread (read + parse) busy " << t_load
-              << "; this thread: queueing " << t_apply << " of which waiting for the flusher " << caller.t_stall
-              << "; flusher thread: GPU calls " << caller.t_gpu << ", formatting " << caller.t_format << ", writing " << caller.t_write
-              << "; waiting for the reader " << t_wait << std::endl;
+    std::cerr << "FamSeq vcf: loop " << now_s() - t_begin << " s; this thread: cutting lines " << t_lines << ", parsing " << t_parse
+              << ", laying out the batch " << t_gather << ", waiting for the flusher " << t_stall << "; flusher thread: GPU calls " << t_gpu
+              << ", formatting " << t_format << ", writing " << t_write << std::endl;
+  if (!o.pack_mode)
+    for (Slot &sl : slots) sl.io.release();
   if (o.pack_mode) {
     std::cout << packer.n_sites << " sites packed";
     if (packer.skipped) std::cout << ", " << packer.skipped << " skipped (PL/GL field is not a plain integer)";
     std::cout << std::endl;
     return packer.close();
   }
-  ok = ok && caller.flush();
+  fout.close();
   famseq_destroy(ctx);
-  return ok;
+  return ok && !fout.fail();
 }
 
 // ---- LK driver (file.cpp:1640-1886) ----------------------------------------------------------
