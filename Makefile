@@ -41,7 +41,7 @@ $(CLI): $(CSRC)/host/famseq_cli.cpp include/famseq_hip.h $(LIB)
 
 # measuring aids: FETCH_SIZE / WRITE_SIZE calibration, the traffic shape's
 # ceiling, sustained fp64 FMA rate, timing of hand-edited generated kernels
-TOOLS := tools/calib_fetch tools/io_ceiling tools/fp64_latency tools/kernel_bench tools/coexec tools/write_sweep
+TOOLS := tools/calib_fetch tools/io_ceiling tools/fp64_latency tools/kernel_bench tools/coexec tools/write_sweep tools/fma_issue
 tools/%: tools/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-unused-value -o $@ $<
 tools: $(TOOLS)

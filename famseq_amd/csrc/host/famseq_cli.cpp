@@ -1453,7 +1453,12 @@ bool run_vcf(const Options &o, const Ped &ped) {
             for (const Item &it : pt.items)
               if (it.site >= 0 && (sl.io.status[pt.base + size_t(it.site)] & 3))
                 std::cout << "Warning: this variant hasn't been calculated: " << std::endl << std::string_view(it.raw, it.raw_len) << std::endl;
-          fout.write(sl.text[t].v.data(), (std::streamsize)sl.text[t].n);
+        }
+        // (one pwrite per thread at its own offset was tried: 0.33 s per 1.47 GB as well — the page cache, not the stream)
+        for (int t = 0; t < sl.n_parts; ++t) fout.write(sl.text[t].v.data(), (std::streamsize)sl.text[t].n);
+        if (fout.fail()) {
+          std::cerr << "cannot write " << o.out_file << std::endl;
+          flush_ok = false;
         }
         t_write += now_s() - t2;
       }

@@ -6,7 +6,8 @@
 // Exact, not approximate: the six digits are round-half-even of the EXACT binary value, as printf gives them.  For
 // 1e-16 <= v < 1e6 (every Phred value: the smallest non-zero one is -10 log10(1 - 2^-53) = 4.8e-16, the largest 99999)
 // v * 10^k with k = 5 - floor(log10 v) <= 22 is the 53-bit significand times 10^k < 2^127 shifted right: one 128-bit
-// product, one shift, remainder compared with one half.  Everything else (zero, larger, smaller, subnormal, negative,
+// product, one shift, remainder compared with one half — taken only when the same product in double arithmetic
+// (exact to 1.2e-10) comes within 1e-6 of a rounding boundary; otherwise that product's nearest integer is the six digits.  Everything else (zero, larger, smaller, subnormal, negative,
 // non-finite) takes the general route.  tests/fmt_g6_check.cpp compares it with snprintf("%g") on 20 M values.
 #pragma once
 #include <charconv>
@@ -42,13 +43,30 @@ inline char *g6(char *out, double v) {
   const int b = be - 1023;
   int X = ((b + 1) * 78913) >> 18;                            // 78913 / 2^18 = log10 2 to 1e-8: exact floor for |b + 1| <= 60
   const int s = -e2;                                          // 33..106
-  unsigned __int128 q;
   uint64_t digits;
+  // Fast route: v * 10^k in double arithmetic is the exact product (10^k is exact for k <= 22) times (1 + e), |e| <= 2^-53,
+  // i.e. within 1.2e-10 of it; unless that leaves the rounding (or the decade) in doubt, its nearest integer is the answer.
+  static const double kPow10d[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16,
+                                     1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  {
+    double x = v * kPow10d[5 - X];
+    if (x < 100000.0 - 1e-6) --X, x = v * kPow10d[5 - X];
+    const double r = std::nearbyint(x);
+    if (x > 100000.0 + 1e-6 && std::fabs(x - r) < 0.5 - 1e-6) {
+      digits = uint64_t(r);
+      if (digits == 1000000) {
+        digits = 100000;
+        if (++X == 6) return g6_general(out, v);
+      }
+      goto have_digits;
+    }
+    X = ((b + 1) * 78913) >> 18;  // in doubt: the exact route decides, from the start
+  }
   for (;;) {
     const int k = 5 - X;                                      // 0..22
     unsigned __int128 n = (unsigned __int128)m * kPow10[k < 19 ? k : 19];
     if (k > 19) n *= kPow10[k - 19];
-    q = n >> s;
+    const unsigned __int128 q = n >> s;
     if (q < 100000) {  // v < 10^X
       --X;
       continue;
@@ -62,6 +80,7 @@ inline char *g6(char *out, double v) {
     }
     break;
   }
+have_digits:
   char d[16] = {0};  // six digits; copied eight bytes at a time below (branch-free: the digit counts are data-dependent)
   {
     const uint32_t v6 = uint32_t(digits), hi = v6 / 1000, lo = v6 - hi * 1000;  // two groups of three digits

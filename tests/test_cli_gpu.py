@@ -256,3 +256,28 @@ def test_packed_pipeline_edge_sizes(tmp_path):
         assert open(back).read() == open(txt).read()
         res = plfile.read_results(str(po))
         assert res["status"].shape[0] == n
+
+
+def test_blocks_parsed_on_many_threads_give_the_single_thread_text(tmp_path):
+    """The vcf driver parses and formats a block of >= 2048 lines on all cores, each thread its own range; a block
+    with GL (non-integer) fields goes to the GPU as fp64 rows rebuilt from every thread's packed integers plus the
+    parsed rows.  probe.vcf's body 200 times over (4,600 lines: every echo / drop / failure / chrX / GL rule in
+    every thread's range) must print the single run's body 200 times over, warnings included."""
+    lines = open(TD + "/probe.vcf").read().split("\n")
+    head = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if l and not l.startswith("#")]
+    big = tmp_path / "big.vcf"
+    big.write_text("\n".join(head + body * 200) + "\n")
+    one, many, serial = tmp_path / "one.vcf", tmp_path / "many.vcf", tmp_path / "serial.vcf"
+    args = ["-pedFile", TD + "/probe.ped", "-a", "-mRate", "0"]
+    w1 = run_cli(["vcf", "-vcfFile", TD + "/probe.vcf"] + args, one)
+    wn = run_cli(["vcf", "-vcfFile", str(big)] + args, many)
+    p = subprocess.run([CLI, "vcf", "-vcfFile", str(big)] + args + ["-output", str(serial)], capture_output=True, text=True,
+                       env=dict(os.environ, FAMSEQ_THREADS="1", FAMSEQ_BATCH="1000"))
+    assert p.returncode == 0
+    got_one = [l for l in open(one).read().split("\n") if l and not l.startswith("#")]
+    got_many = [l for l in open(many).read().split("\n") if l and not l.startswith("#")]
+    assert got_many == got_one * 200
+    assert open(serial).read() == open(many).read()
+    n_warn = w1.count("Warning: this variant hasn't been calculated")
+    assert n_warn == 2 and wn.count("Warning: this variant hasn't been calculated") == 200 * n_warn
