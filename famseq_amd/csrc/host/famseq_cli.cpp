@@ -1257,27 +1257,28 @@ bool run_vcf(const Options &o, const Ped &ped) {
     uint32_t raw_len;
     uint32_t prefix_len;   // site: columns 1-9 without the tab after FORMAT
     uint32_t n_fmt;        // site: FORMAT keys (a missing sample prints that many "NA:")
-    int32_t site;          // index among this thread's sites; -1: an echoed line, text = echo[echo_off, +echo_len)
+    int32_t site;          // the line's index in the block = its site in the batch; -1: an echoed line, text = echo[echo_off, +echo_len)
     uint32_t echo_off, echo_len;
+    uint32_t smp;          // site: its samples are samples[smp, +n_seq)
   };
   struct Part {
     vector<Item> items;
     vector<char> echo;
-    vector<uint16_t> pl;                 // [site][n_seq][3]; 0xFFFF x3 = the sample's row stays {1,1,1}
-    vector<uint8_t> flags;               // [site]
-    vector<Record::Sample> samples;      // [site][n_seq]
+    vector<Record::Sample> samples;      // n_seq per site
     vector<uint32_t> explicit_sites;     // sites with a PL/GL field that is not a plain integer ...
     vector<double> explicit_lk;          // ... and their N x 3 likelihoods (the batch then goes in as fp64)
-    size_t base = 0;                     // index of this thread's first site in the batch
     bool any_failed = false;
     void clear() {
-      items.clear(), echo.clear(), pl.clear(), flags.clear(), samples.clear(), explicit_sites.clear(), explicit_lk.clear();
+      items.clear(), echo.clear(), samples.clear(), explicit_sites.clear(), explicit_lk.clear();
       any_failed = false;
     }
   };
 
-  // One input line -> an Item (or nothing).  Pure function of the line (no shared state).
-  auto parse_line = [&](std::string_view line, Part &out) {
+  // One input line -> an Item (or nothing).  Pure function of the line (no shared state).  Line q of a block is site q of
+  // the batch: a site's flag byte and packed PLs are written where the GPU call will read them (flags_q, pl16: the
+  // caller has set them to "all samples missing", which is what a line that is no site stays — computed and ignored;
+  // compacting the sites first cost a pass over the batch, and the GPU idles nine tenths of the loop).
+  auto parse_line = [&](std::string_view line, size_t q, Part &out, uint8_t *flags_q, uint16_t *pl16) {
     if (line[0] == '#') return;
     thread_local vector<std::string_view> t, fmt, sub;
     thread_local vector<double> lkrow;
@@ -1294,7 +1295,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
         out.echo.insert(out.echo.end(), t[9 + c].begin(), t[9 + c].end());
         out.echo.push_back('\t');
       }
-      out.items.push_back(Item{nullptr, 0, 0, 0, -1, uint32_t(at), uint32_t(out.echo.size() - at)});
+      out.items.push_back(Item{nullptr, 0, 0, 0, -1, uint32_t(at), uint32_t(out.echo.size() - at), 0});
     };
     if (use_loc) {
       const int c = chrom_number(string(t[0]));
@@ -1335,12 +1336,9 @@ bool run_vcf(const Options &o, const Ped &ped) {
       return;
     }
     const char *base = line.data();
-    const size_t site = out.flags.size();
     out.items.push_back(Item{base, uint32_t(line.size()), uint32_t(t[8].data() + t[8].size() - base), uint32_t(fmt.size()),
-                             int32_t(site), 0, 0});
-    out.flags.push_back(flags);
-    out.pl.resize((site + 1) * 3 * n_seq, uint16_t(0xFFFF));  // 0xFFFF x3 = missing sample
-    uint16_t *pl16 = &out.pl[site * 3 * n_seq];
+                             int32_t(q), 0, 0, uint32_t(out.samples.size())});
+    *flags_q = flags;
     lkrow.assign(N3, 1.0);
     bool integral = true;
     size_t col = 0;
@@ -1361,14 +1359,14 @@ bool run_vcf(const Options &o, const Ped &ped) {
       }
     }
     if (!integral) {
-      out.explicit_sites.push_back(uint32_t(site));
+      out.explicit_sites.push_back(uint32_t(q));
       out.explicit_lk.insert(out.explicit_lk.end(), lkrow.begin(), lkrow.end());
     }
   };
 
-  // ---- the pipeline.  A block of input lines is ONE batch: this thread cuts it into lines and has it parsed on all
-  // cores (each thread its contiguous range, into its own Part), lays the parts' packed PLs end to end in a pinned
-  // buffer and hands the block to the flusher thread — GPU call (famseq_bn_call_batch: posterior, Phred scaling and
+  // ---- the pipeline.  A block of input lines is ONE batch: this thread cuts it into lines, has it parsed on all
+  // cores (each thread its contiguous range, into its own Part and into its range of the batch's pinned arrays)
+  // and hands the block to the flusher thread — GPU call (famseq_bn_call_batch: posterior, Phred scaling and
   // genotype call on the device), formatting (each thread the range it parsed), one write per thread — while it goes on
   // with the next block in the other slot.  (Before: lines copied one by one out of an ifstream, parsed results moved
   // one by one into the batch by this thread, 0.94 of the loop's 1.0 s per 1 M ten-member sites.)
@@ -1380,8 +1378,10 @@ bool run_vcf(const Options &o, const Ped &ped) {
     vector<std::string_view> lines;
     vector<Part> parts;
     int n_parts = 0;
-    size_t n_sites = 0;
+    size_t n_sites = 0;  // = lines of the block
     bool packed = true;
+    vector<uint16_t> pk_pl;     // pack mode: the block's arrays live here, nothing is pinned
+    vector<uint8_t> pk_flags;
     PlBatch io;          // pinned: pl + flags in, gpp / fpp / fgt / status out
     vector<double> lk;   // fp64 input, only for a block with a non-integer PL/GL field
     vector<TextBuf> text;
@@ -1418,8 +1418,8 @@ bool run_vcf(const Options &o, const Ped &ped) {
             if (it.site < 0) {
               out.put(pt.echo.data() + it.echo_off, it.echo_len);
             } else {
-              const size_t s = pt.base + size_t(it.site);
-              const Record::Sample *sm = &pt.samples[size_t(it.site) * k];
+              const size_t s = size_t(it.site);
+              const Record::Sample *sm = &pt.samples[it.smp];
               out.put(it.raw, it.prefix_len);  // columns 1-8 + FORMAT
               out.put(":GPP:FPP:FGT\t", 13);
               if (sl.io.status[s] & 3) {  // file.cpp:607-620
@@ -1451,7 +1451,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
           const Part &pt = sl.parts[t];
           if (pt.any_failed)  // the reference's warning on stdout, in input order (file.cpp:607-612)
             for (const Item &it : pt.items)
-              if (it.site >= 0 && (sl.io.status[pt.base + size_t(it.site)] & 3))
+              if (it.site >= 0 && (sl.io.status[it.site] & 3))
                 std::cout << "Warning: this variant hasn't been calculated: " << std::endl << std::string_view(it.raw, it.raw_len) << std::endl;
         }
         // (one pwrite per thread at its own offset was tried: 0.33 s per 1.47 GB as well — the page cache, not the stream)
@@ -1492,67 +1492,72 @@ bool run_vcf(const Options &o, const Ped &ped) {
     sl.n_parts = nl < 2048 ? 1 : (int)n_threads;
     double t2 = now_s();
     t_lines += t2 - t1;
+    if (o.pack_mode) {
+      sl.pk_pl.resize(nl * 3 * n_seq), sl.pk_flags.resize(nl);
+    } else if (sl.io.cap < nl) {  // pinned, sized by the first block (a short file does not pay for 65,536 sites)
+      sl.io.release();
+      sl.io = PlBatch();
+      if (!sl.io.alloc(nl, std::max<size_t>(n_seq, 1))) {
+        std::cerr << "cannot allocate pinned host buffers" << std::endl;
+        ok = false;
+        to_driver.put(i);
+        break;
+      }
+    }
+    uint16_t *const pl_arr = o.pack_mode ? sl.pk_pl.data() : sl.io.pl;
+    uint8_t *const flags_arr = o.pack_mode ? sl.pk_flags.data() : sl.io.flags;
     on_threads(sl.n_parts, [&](int t) {
       Part &pt = sl.parts[t];
       pt.clear();
-      for (size_t q = nl * t / sl.n_parts, e = nl * (t + 1) / sl.n_parts; q < e; ++q) parse_line(sl.lines[q], pt);
+      const size_t lo = nl * t / sl.n_parts, hi = nl * (t + 1) / sl.n_parts;
+      std::memset(flags_arr + lo, 0, hi - lo);
+      std::memset(pl_arr + lo * 3 * n_seq, 0xFF, (hi - lo) * 6 * n_seq);  // 0xFFFF x3 = missing sample
+      for (size_t q = lo; q < hi; ++q) parse_line(sl.lines[q], q, pt, flags_arr + q, pl_arr + q * 3 * n_seq);
     });
     double t3 = now_s();
     t_parse += t3 - t2;
-    size_t total = 0;
     bool packed = true;
+    size_t real = 0;
     for (int t = 0; t < sl.n_parts; ++t) {
-      sl.parts[t].base = total;
-      total += sl.parts[t].flags.size();
       packed = packed && sl.parts[t].explicit_sites.empty();
+      real += sl.parts[t].samples.size();
     }
-    sl.n_sites = total, sl.packed = packed;
+    sl.n_sites = real ? nl : 0, sl.packed = packed;  // a block without a single site (or without a sequenced sample) calls nothing
     if (o.pack_mode) {  // records of the integer sites, in input order; nothing goes to the GPU
       for (int t = 0; t < sl.n_parts; ++t) {
         const Part &pt = sl.parts[t];
         size_t x = 0;
-        for (size_t q = 0; q < pt.flags.size(); ++q) {
-          if (x < pt.explicit_sites.size() && pt.explicit_sites[x] == q) {
+        for (const Item &it : pt.items) {
+          if (it.site < 0) continue;
+          if (x < pt.explicit_sites.size() && pt.explicit_sites[x] == uint32_t(it.site)) {
             ++x, packer.skipped++;
             continue;
           }
-          packer.add(pt.flags[q], &pt.pl[q * 3 * n_seq]);
+          packer.add(flags_arr[it.site], pl_arr + size_t(it.site) * 3 * n_seq);
         }
       }
       t_gather += now_s() - t3;
       to_driver.put(i);
       continue;
     }
-    if (!packed) sl.lk.resize(total * N3);
-    if (sl.io.cap < total) {  // pinned, sized by the first block (a short file does not pay for 65,536 sites)
-      sl.io.release();
-      if (!sl.io.alloc(total, std::max<size_t>(n_seq, 1))) {
-        std::cerr << "cannot allocate pinned host buffers" << std::endl;
-        ok = false;
-        sl.io = PlBatch();
-        to_driver.put(i);
-        break;
-      }
-    }
-    on_threads(sl.n_parts, [&](int t) {  // the parts end to end: what the GPU call reads
-      const Part &pt = sl.parts[t];
-      const size_t n = pt.flags.size();
-      if (n == 0) return;
-      std::memcpy(sl.io.flags + pt.base, pt.flags.data(), n);
-      std::memcpy(sl.io.pl + pt.base * 3 * n_seq, pt.pl.data(), n * 6 * n_seq);
-      if (packed) return;
+    if (!packed) {
       // fp64 rows: the table's value for every integer field (what the parser computed for it), the parsed rows of the others
-      double *rows = sl.lk.data() + pt.base * N3;
-      std::fill(rows, rows + n * N3, 1.0);
-      for (size_t q = 0; q < n; ++q)
-        for (size_t j = 0; j < n_seq; ++j) {
-          const uint16_t *p = &pt.pl[(q * n_seq + j) * 3];
-          if (p[0] == 0xFFFF && p[1] == 0xFFFF && p[2] == 0xFFFF) continue;
-          for (int g = 0; g < 3; ++g) rows[q * N3 + size_t(3) * seq_members[j] + g] = pl.value(p[g]);
-        }
-      for (size_t x = 0; x < pt.explicit_sites.size(); ++x)
-        std::copy(&pt.explicit_lk[x * N3], &pt.explicit_lk[(x + 1) * N3], rows + size_t(pt.explicit_sites[x]) * N3);
-    });
+      sl.lk.resize(nl * N3);
+      on_threads(sl.n_parts, [&](int t) {
+        const Part &pt = sl.parts[t];
+        const size_t lo = nl * t / sl.n_parts, hi = nl * (t + 1) / sl.n_parts;
+        double *rows = sl.lk.data();
+        std::fill(rows + lo * N3, rows + hi * N3, 1.0);
+        for (size_t q = lo; q < hi; ++q)
+          for (size_t j = 0; j < n_seq; ++j) {
+            const uint16_t *p = &pl_arr[(q * n_seq + j) * 3];
+            if (p[0] == 0xFFFF && p[1] == 0xFFFF && p[2] == 0xFFFF) continue;
+            for (int g = 0; g < 3; ++g) rows[q * N3 + size_t(3) * seq_members[j] + g] = pl.value(p[g]);
+          }
+        for (size_t x = 0; x < pt.explicit_sites.size(); ++x)
+          std::copy(&pt.explicit_lk[x * N3], &pt.explicit_lk[(x + 1) * N3], rows + size_t(pt.explicit_sites[x]) * N3);
+      });
+    }
     t_gather += now_s() - t3;
     to_flusher.put(i);
   }
@@ -1561,7 +1566,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
   ok = ok && flush_ok;
   if (std::getenv("FAMSEQ_TIMING") && !o.pack_mode)
     std::cerr << "FamSeq vcf: loop " << now_s() - t_begin << " s; this thread: cutting lines " << t_lines << ", parsing " << t_parse
-              << ", laying out the batch " << t_gather << ", waiting for the flusher " << t_stall << "; flusher thread: GPU calls " << t_gpu
+              << ", fp64 rows / pack records " << t_gather << ", waiting for the flusher " << t_stall << "; flusher thread: GPU calls " << t_gpu
               << ", formatting " << t_format << ", writing " << t_write << std::endl;
   if (!o.pack_mode)
     for (Slot &sl : slots) sl.io.release();
