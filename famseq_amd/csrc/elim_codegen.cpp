@@ -499,9 +499,13 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
   // ROW: the lane's LDS row, W3 doubles padded to an odd count (conflict-free ds_read_b64); a
   // generator may ask for more (spare slots it uses itself), odd again
   const int N = m.n_members, W3 = 3 * N, ROW = (row_doubles > 0 ? row_doubles : W3) | 1;
-  // Prefetching the next chunk costs W3 doubles of registers next to the W3 marginals; on MI355X it
-  // pays while it does not spill (ped5: +14 %); beyond the limits below it spills and loses.
-  int prefetch_max_n = regs_l ? 7 : 10;  // the register-resident shell already holds the row: less room
+  // Prefetching the next chunk costs W3 doubles of registers next to the W3 marginals; it pays while it costs
+  // neither a spill nor a wave.  The register-resident shell (the enumeration kernel) already holds the row: with the
+  // prefetch a five-member kernel needs 184 VGPRs = two waves per SIMD, without it 3 fit (its 34 KB of LDS rows
+  // allow four workgroups per CU) and 8 M five-member sites take 0.760 instead of 0.796 ms; six members 0.598
+  // against 0.612, seven 0.963 against 0.986 (the prefetch spills there); trios and quads keep it (0.376 against
+  // 0.387, 0.585 against 0.583: tools/kernel_bench, profiles/r02c/exp_small_peds_3x.txt, exp_sib678.txt).
+  int prefetch_max_n = regs_l ? 4 : 10;
   if (const char *e = std::getenv("FAMSEQ_PREFETCH_MAXN")) prefetch_max_n = std::atoi(e);  // tuning aid
   // call_mode: the fused call path's form of the kernel (famseq_bn_call_batch): input packed PLs or fp64
   // rows, outputs GPP / FPP / FGT / status only, arguments behind call_g; no prefetch (the kernel is

@@ -275,9 +275,14 @@ def test_blocks_parsed_on_many_threads_give_the_single_thread_text(tmp_path):
     p = subprocess.run([CLI, "vcf", "-vcfFile", str(big)] + args + ["-output", str(serial)], capture_output=True, text=True,
                        env=dict(os.environ, FAMSEQ_THREADS="1", FAMSEQ_BATCH="1000"))
     assert p.returncode == 0
-    got_one = [l for l in open(one).read().split("\n") if l and not l.startswith("#")]
-    got_many = [l for l in open(many).read().split("\n") if l and not l.startswith("#")]
-    assert got_many == got_one * 200
-    assert open(serial).read() == open(many).read()
+    # (compared as everywhere in this file: a 23-site batch and a 4,600-site batch run different kernels, whose
+    # posteriors differ in the last bits, which -10 log10(1 - 1e-12) magnifies into the fourth digit of a 4e-12)
+    text_one = open(one).read().split("\n")
+    head_one = [l for l in text_one if l.startswith("#")]
+    body_one = [l for l in text_one if l and not l.startswith("#")]
+    expect = tmp_path / "expect.vcf"
+    expect.write_text("\n".join(head_one + body_one * 200) + "\n")
+    assert assert_same_output(many, expect) == 200 * assert_same_output(one, one) > 0
+    assert_same_output(serial, expect)
     n_warn = w1.count("Warning: this variant hasn't been calculated")
     assert n_warn == 2 and wn.count("Warning: this variant hasn't been calculated") == 200 * n_warn
