@@ -259,9 +259,16 @@ class Gen {
     // One division per row and three products (the sums differ from the reference's in their last bits already, by
     // summation order; 35 -> 25 divisions per five-member site, each ten instructions).  A row sum in the subnormal
     // range, whose reciprocal overflows, keeps the three divisions behind a real branch.
+    bool div_rows = false;
+    if (const char *e = std::getenv("FAMSEQ_LANE_DIVROWS")) div_rows = std::atoi(e) != 0;  // tuning aid: three divisions per row
     for (int p = 0; p < s_.N; ++p) {
       auto out = [&](int g) { return O_ + "[" + std::to_string(3 * p + g) + "]"; };
       const std::string b = "b" + std::to_string(p);
+      if (div_rows) {
+        o_ << "      { const double s = (" << b << "_0 + " << b << "_1) + " << b << "_2; if (s <= 0) bn_fail = true;\n        " << out(0) << " = "
+           << b << "_0 / s; " << out(1) << " = " << b << "_1 / s; " << out(2) << " = " << b << "_2 / s; }\n";
+        continue;
+      }
       o_ << "      { const double s = (" << b << "_0 + " << b << "_1) + " << b << "_2; if (s <= 0) bn_fail = true;\n"
          << "        if (s < 1e-290) { asm volatile(\"\" ::: \"memory\"); " << out(0) << " = " << b << "_0 / s; " << out(1) << " = " << b
          << "_1 / s; " << out(2) << " = " << b << "_2 / s; }\n"

@@ -423,12 +423,10 @@ int parallel_ranges(size_t n, F f) {
   return (int)t;
 }
 
-// Queue of output records between the drivers' line loops and the GPU.  Records (pass-through lines and
-// sites) are kept in input order; a full batch is handed to a flusher thread — GPU call
+// Queue of output records between the LK driver's line loop and the GPU (the vcf driver has its own block
+// pipeline, run_vcf).  Records are kept in input order; a full batch is handed to a flusher thread — GPU call
 // (famseq_bn_call_batch: posterior, Phred scaling and genotype call all on the device), formatting on all
 // cores, one write per formatting thread — while the driver's thread goes on filling the next batch.
-// (Round 1 did all of it on the driver's thread: of 1.14 s per 1 M ten-member VCF lines it spent 0.07 s in
-// GPU calls, 0.28 s formatting, 0.33 s in one ofstream::write per line and 0.43 s queueing.)
 class BatchCaller {
  public:
   double t_gpu = 0, t_format = 0, t_write = 0, t_stall = 0;  // FAMSEQ_TIMING: where the flusher spends its time; driver waiting for it
