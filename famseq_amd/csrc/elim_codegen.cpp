@@ -524,7 +524,8 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
   if (const char *e = std::getenv("FAMSEQ_CHUNK_STRIDE")) strided = std::atoi(e) != 0;  // tuning aid
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
-    << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
+    // (the in-process compiler, hiprtc, brings the device built-ins itself and has no include path for the header)
+    << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n#pragma clang fp contract(off)\n"
     << "#define W3 " << W3 << "\n#define ROW " << ROW << "\n#define BT " << bt << "\n"
     // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e.
     // every barrier would wait for this wave's global stores to reach memory; nothing here hands

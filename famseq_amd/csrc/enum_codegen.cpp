@@ -737,7 +737,8 @@ std::string grouped_shell(const famseq_model &m, const std::string &comment, con
   const int N = m.n_members, W3 = 3 * N, ROW = (row_doubles > 0 ? row_doubles : W3) | 1;
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
-    << "#include <hip/hip_runtime.h>\n#pragma clang fp contract(off)\n"
+    // (the in-process compiler, hiprtc, brings the device built-ins itself and has no include path for the header)
+    << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n#pragma clang fp contract(off)\n"
     << "#define W3 " << W3 << "\n#define ROW " << ROW << "\n#define BT " << bt << "\n#define G " << group << "\n#define SPC (BT / G)\n"
     << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
     // rows of the groups' first lanes -> global, coalesced

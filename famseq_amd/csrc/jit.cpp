@@ -105,6 +105,73 @@ int read_res(const std::string &obj) {
 
 }  // namespace
 
+namespace {
+
+// The in-process compiler: libhiprtc, which ships with the HIP runtime itself.  No hipcc on the host, no child
+// process (so it also works where a process that has initialised the GPU must not exec: under rocprofv3), and the
+// same code: for the ten-member enumeration kernel hiprtc and `hipcc --genco` emit identical instruction streams
+// (4,835 instructions compared).  Loaded on first use with dlopen, so a host without it still has the cache and hipcc.
+struct Rtc {
+  typedef struct _hiprtcProgram *Program;
+  int (*create)(Program *, const char *, const char *, int, const char **, const char **) = nullptr;
+  int (*compile)(Program, int, const char **) = nullptr;
+  int (*log_size)(Program, size_t *) = nullptr;
+  int (*log)(Program, char *) = nullptr;
+  int (*code_size)(Program, size_t *) = nullptr;
+  int (*code)(Program, char *) = nullptr;
+  int (*destroy)(Program *) = nullptr;
+  bool ok = false;
+};
+
+const Rtc &rtc() {
+  static const Rtc r = [] {
+    Rtc x;
+    void *h = nullptr;
+    for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return x;
+    auto sym = [&](const char *n) { return dlsym(h, n); };
+    x.create = reinterpret_cast<decltype(x.create)>(sym("hiprtcCreateProgram"));
+    x.compile = reinterpret_cast<decltype(x.compile)>(sym("hiprtcCompileProgram"));
+    x.log_size = reinterpret_cast<decltype(x.log_size)>(sym("hiprtcGetProgramLogSize"));
+    x.log = reinterpret_cast<decltype(x.log)>(sym("hiprtcGetProgramLog"));
+    x.code_size = reinterpret_cast<decltype(x.code_size)>(sym("hiprtcGetCodeSize"));
+    x.code = reinterpret_cast<decltype(x.code)>(sym("hiprtcGetCode"));
+    x.destroy = reinterpret_cast<decltype(x.destroy)>(sym("hiprtcDestroyProgram"));
+    x.ok = x.create && x.compile && x.log_size && x.log && x.code_size && x.code && x.destroy;
+    return x;
+  }();
+  return r;
+}
+
+// true: `code` holds the code object and `log` the compiler's remarks.  false with `log` empty: no in-process
+// compiler here (the caller may try hipcc); false with `log` set: the compiler rejected the source.
+bool rtc_compile(const std::string &source, std::string &code, std::string &log) {
+  code.clear(), log.clear();
+  if (std::getenv("FAMSEQ_NO_HIPRTC")) return false;  // test aid: the hipcc route
+  const Rtc &r = rtc();
+  if (!r.ok) return false;
+  Rtc::Program prog = nullptr;
+  if (r.create(&prog, source.c_str(), "famseq_kernel.hip", 0, nullptr, nullptr) != 0) return false;
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage"};
+  const int rc = r.compile(prog, 5, opts);
+  size_t n = 0;
+  if (r.log_size(prog, &n) == 0 && n > 1) {
+    log.resize(n);
+    (void)r.log(prog, &log[0]);
+  }
+  bool good = rc == 0 && r.code_size(prog, &n) == 0 && n > 0;
+  if (good) {
+    code.resize(n);
+    good = r.code(prog, &code[0]) == 0;
+  }
+  (void)r.destroy(&prog);
+  if (!good && log.empty()) log = "hiprtcCompileProgram failed (" + std::to_string(rc) + ")";
+  return good;
+}
+
+}  // namespace
+
 std::string jit_compile(const std::string &source, int *scratch_bytes, bool note_suffices) {
   // One compilation at a time per process: famseq_bn_batch*_sharded runs a host thread per ctx, and
   // with a cold cache every one of them arrives here with the same source.  The first compiles,
@@ -147,13 +214,36 @@ std::string jit_compile(const std::string &source, int *scratch_bytes, bool note
     if (scratch_bytes) *scratch_bytes = 0;
     return obj;
   }
+  const std::string uniq = std::to_string((long)getpid()) + "_" + std::to_string(serial.fetch_add(1));
+  const std::string tmp = obj + "." + uniq + ".tmp";
+  auto publish = [&](int scratch) {  // resource note first, then the object: whoever sees the object also finds the note
+    const std::string res_tmp = tmp + ".res";
+    std::ofstream rf(res_tmp.c_str());
+    rf << scratch << "\n";
+    rf.close();
+    ::rename(res_tmp.c_str(), (dir + "/" + name + ".res").c_str());
+    if (scratch_bytes) *scratch_bytes = scratch;
+    ::rename(tmp.c_str(), obj.c_str());  // atomic publish: concurrent ranks may compile the same kernel
+    if (std::getenv("FAMSEQ_KEEP_SRC")) std::ofstream((dir + "/" + name + ".hip").c_str()) << source;  // debugging aid
+  };
+  {
+    std::string code, log;
+    if (rtc_compile(source, code, log)) {
+      std::ofstream f(tmp.c_str(), std::ios::binary);
+      f.write(code.data(), (std::streamsize)code.size());
+      f.close();
+      if (!f) throw std::runtime_error("cannot write " + tmp);
+      publish(parse_scratch(log));
+      return obj;
+    }
+    if (!log.empty()) throw std::runtime_error("kernel compilation failed (hiprtc): " + log.substr(0, 2000));
+  }
+  // no in-process compiler on this host: hipcc as a child process
   if (const char *why = profiler_env())
     throw std::runtime_error(std::string("kernel ") + name + " is not in the cache (" + dir + ") and a profiler is attached ($" +
-                             why + "): build it outside the profiler first (a plan-only ctx with the same options, "
-                             "or __graft_entry__.build())");
-  const std::string uniq = std::to_string((long)getpid()) + "_" + std::to_string(serial.fetch_add(1));
+                             why + "), this host has no libhiprtc to compile it in-process: build it outside the profiler first "
+                             "(a plan-only ctx with the same options, or __graft_entry__.build())");
   const std::string src = dir + "/" + name + "." + uniq + ".hip";
-  const std::string tmp = obj + "." + uniq + ".tmp";
   {
     std::ofstream f(src.c_str());
     f << source;
@@ -178,21 +268,8 @@ std::string jit_compile(const std::string &source, int *scratch_bytes, bool note
   if (rc != 0 || !exists(tmp)) {
     throw std::runtime_error("kernel compilation failed (" + cmd + "): " + log.substr(0, 2000));
   }
-  const int scratch = parse_scratch(log);
-  {  // resource note first, then the object: whoever sees the object also finds the note
-    const std::string res_tmp = tmp + ".res";
-    std::ofstream rf(res_tmp.c_str());
-    rf << scratch << "\n";
-    rf.close();
-    ::rename(res_tmp.c_str(), (dir + "/" + name + ".res").c_str());
-  }
-  if (scratch_bytes) *scratch_bytes = scratch;
-  ::rename(tmp.c_str(), obj.c_str());  // atomic publish: concurrent ranks may compile the same kernel
-  if (std::getenv("FAMSEQ_KEEP_SRC")) {  // debugging aid: keep the generated source next to the object
-    ::rename(src.c_str(), (dir + "/" + name + ".hip").c_str());
-  } else {
-    ::unlink(src.c_str());
-  }
+  publish(parse_scratch(log));
+  ::unlink(src.c_str());
   ::unlink((src + ".log").c_str());
   return obj;
 }

@@ -100,6 +100,7 @@ void drive(const Ped &p) {
 
 int main() {
   setenv("FAMSEQ_HIPCC", "/bin/false", 1);  // the generators run; nothing is compiled
+  setenv("FAMSEQ_NO_HIPRTC", "1", 1);       // (neither in-process nor by hipcc)
   setenv("FAMSEQ_QUIET", "1", 1);
   char tmpl[] = "/tmp/famseq_asan_XXXXXX";
   const char *dir = mkdtemp(tmpl);

@@ -112,3 +112,33 @@ def test_host_code_is_clean_under_asan_and_ubsan():
     r = subprocess.run(["make", "-s", "-C", ROOT, "asan"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "asan_host_check: ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
+def _compile_in_subprocess(tmp_path, extra_env):
+    """A plan-only context compiles the trio's sum-product kernel into an empty cache; (returncode, output, files)."""
+    import subprocess
+    import sys
+
+    code = ("import famseq_amd as fs\n"
+            "ctx = fs.Context(fs.make_model(fs.synthetic_pedigree('trio')), device=-1)\n"
+            "ctx.set_option('engine', fs.ENGINE_ELIM)\n"
+            "print(ctx.plan()['elim_code_object'])\n")
+    env = dict(os.environ, FAMSEQ_KERNEL_CACHE=str(tmp_path), FAMSEQ_QUIET="1", **extra_env)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    return p.returncode, p.stdout + p.stderr, sorted(f.name for f in tmp_path.iterdir())
+
+
+def test_kernels_compile_in_process_without_hipcc(tmp_path):
+    """jit.cpp compiles through libhiprtc (part of the HIP runtime): no hipcc on the host, no child process (so also
+    where a profiler is attached and a process that has initialised the GPU must not exec: tests/test_gpu_multi.py)."""
+    rc, out, files = _compile_in_subprocess(tmp_path, {"FAMSEQ_HIPCC": "/nonexistent/hipcc"})
+    assert rc == 0, out
+    assert any(f.endswith(".hsaco") for f in files) and all(f.endswith((".hsaco", ".res")) for f in files), files
+    obj = [f for f in files if f.endswith(".hsaco")][0]
+    assert open(os.path.join(str(tmp_path), obj), "rb").read(4) == b"\x7fELF"
+
+
+def test_no_compiler_at_all_is_an_error_not_a_silent_path(tmp_path):
+    rc, out, files = _compile_in_subprocess(tmp_path, {"FAMSEQ_HIPCC": "/nonexistent/hipcc", "FAMSEQ_NO_HIPRTC": "1"})
+    assert rc != 0 and "compilation failed" in out, out
+    assert not any(f.endswith(".hsaco") for f in files), files

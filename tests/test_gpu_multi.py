@@ -88,6 +88,7 @@ def test_lane_kernel_failure_is_reported(tmp_path, monkeypatch, capfd):
     stderr once and in the plan; asking for the lane kernel explicitly is an error."""
     monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
     monkeypatch.setenv("FAMSEQ_HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("FAMSEQ_NO_HIPRTC", "1")
     c, lk, flags = _ped10_batch(300)
     model = fs.make_model(c.pedigree())
     ctx = fs.Context(model, lane_min_sites=1)
@@ -106,13 +107,29 @@ def test_lane_kernel_failure_is_reported(tmp_path, monkeypatch, capfd):
 
 
 def test_jit_refuses_to_spawn_a_compiler_under_a_profiler(tmp_path, monkeypatch):
+    """(Only a host without libhiprtc ever gets here: the in-process compiler needs no child process.)"""
     monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
     monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    monkeypatch.setenv("FAMSEQ_NO_HIPRTC", "1")
     monkeypatch.setenv("FAMSEQ_QUIET", "1")
     c, _, _ = _ped10_batch(1)
     ctx = fs.Context(fs.make_model(c.pedigree()), device=-1)
     with pytest.raises(fs.FamseqError, match="profiler is attached"):
         ctx.set_option("engine", fs.ENGINE_ELIM)
+    ctx.close()
+
+
+def test_jit_compiles_in_process_under_a_profiler(tmp_path, monkeypatch):
+    """With libhiprtc the compile needs no child process, so a profiler's environment does not stop it (round 1
+    ran hipcc through std::system from the profiled process: an exec from a GPU-initialised process)."""
+    monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    monkeypatch.setenv("FAMSEQ_HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("FAMSEQ_QUIET", "1")
+    c, _, _ = _ped10_batch(1)
+    ctx = fs.Context(fs.make_model(c.pedigree()), device=-1)
+    ctx.set_option("engine", fs.ENGINE_ELIM)
+    assert ctx.plan()["elim_code_object"].startswith(str(tmp_path))
     ctx.close()
 
 
