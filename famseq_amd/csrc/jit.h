@@ -2,10 +2,11 @@
 //
 // Some engines of this library are generated as straight-line HIP for one pedigree (its
 // topology fixes every index, so all per-site state lives in registers).  The source is
-// compiled with hipcc --genco for gfx950 and cached on disk by content hash:
+// compiled for gfx950 — in-process through libhiprtc; by `hipcc --genco` as a child process on a host
+// without it — and cached on disk by content hash:
 //   $FAMSEQ_KERNEL_CACHE when set; otherwise <dir of libfamseq_hip.so>/kernels/<hash>.hsaco
 //   (in-tree: prebuilt objects travel with the library), then /tmp/famseq_kernels_<uid>.
-// Compiler: $FAMSEQ_HIPCC or /opt/rocm/bin/hipcc.
+// Fallback compiler: $FAMSEQ_HIPCC or /opt/rocm/bin/hipcc ($FAMSEQ_NO_HIPRTC=1, a test aid, goes straight to it).
 #ifndef FAMSEQ_JIT_H_
 #define FAMSEQ_JIT_H_
 

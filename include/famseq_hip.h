@@ -123,7 +123,7 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *   "call_kernels"  1 = build the generated kernels' fused call-path forms now (famseq_bn_call_batch would on
  *                   its first call)
  *   "engine"        FAMSEQ_ENGINE_ENUM (default) or FAMSEQ_ENGINE_ELIM; selecting ELIM generates the
- *                   kernel for this pedigree, compiles it with hipcc (cached on disk) and fails with
+ *                   kernel for this pedigree, compiles it (libhiprtc in-process; cached on disk) and fails with
  *                   FAMSEQ_E_ARG on a pedigree whose loops need more than three conditioned members
  * Returns 0 or FAMSEQ_E_ARG. */
 int famseq_set_option(famseq_ctx *ctx, const char *key, int64_t value);
