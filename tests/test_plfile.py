@@ -75,6 +75,49 @@ def test_pack_matches_python_site_rules(tmp_path):
             assert pl.max() == 65534  # test.vcf holds a PL of 84692 for ind03: clamped (exactly 0 either way)
 
 
+def _pack(vcf, out, env=None, stdin=None):
+    p = subprocess.run([CLI, "pack", "-vcfFile", str(vcf), "-pedFile", TD + "/fam01.ped", "-output", str(out)], capture_output=True,
+                       text=True, env=env, stdin=stdin)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return open(out, "rb").read()
+
+
+def test_input_shapes_the_line_reader_must_take(tmp_path):
+    """The vcf driver cuts lines out of the memory-mapped file (std::getline's lines): the last line counts without a
+    newline, processing stops at the first empty line as in the reference (file.cpp: `line.size() < 2`), what cannot be
+    mapped (a pipe) is read whole, and the bytes do not depend on how many threads parse a block or how long a block is.
+    TestData/test.vcf's body six times over, so that a block has more than the 2,048 lines one thread takes alone."""
+    import gzip
+
+    lines = gzip.open(TD + "/test_full.vcf.gz", "rt").read().split("\n")
+    head = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if l and not l.startswith("#")]
+    text = "\n".join(head + body * 6) + "\n"
+    full = tmp_path / "full.vcf"
+    full.write_text(text)
+    want = _pack(full, tmp_path / "full.fspl")
+    hdr, flags, pl = plfile.read_plfile(tmp_path / "full.fspl")
+    assert len(flags) == 6 * 12  # the 12 computable sites of test.vcf for fam01, each time
+    # no newline after the last line
+    (tmp_path / "nonl.vcf").write_text(text[:-1])
+    assert _pack(tmp_path / "nonl.vcf", tmp_path / "nonl.fspl") == want
+    # one thread, short blocks
+    env = dict(os.environ, FAMSEQ_THREADS="1", FAMSEQ_BATCH="97")
+    assert _pack(full, tmp_path / "serial.fspl", env=env) == want
+    # through a pipe: nothing to map
+    with open(full, "rb") as f:
+        p = subprocess.Popen(["cat"], stdin=f, stdout=subprocess.PIPE)
+        got = _pack("/dev/stdin", tmp_path / "pipe.fspl", stdin=p.stdout)
+        p.wait()
+    assert got == want
+    # an empty line ends the input: only what stands before it is packed
+    n_before = len(head) + len(body) * 2
+    cut = text.split("\n")
+    (tmp_path / "cut.vcf").write_text("\n".join(cut[:n_before] + [""] + cut[n_before:]))
+    _pack(tmp_path / "cut.vcf", tmp_path / "cut.fspl")
+    assert len(plfile.read_plfile(tmp_path / "cut.fspl")[1]) == 2 * 12
+
+
 def test_python_writer_roundtrip(tmp_path):
     rng = np.random.RandomState(2)
     pl = rng.randint(0, 65536, size=(1000, 5, 3)).astype(np.uint16)
