@@ -60,8 +60,18 @@ build/asan/%.o: $(CSRC)/% $(wildcard $(CSRC)/*.h) include/famseq_hip.h
 	g++ $(ASAN_FLAGS) -c $< -o $@
 build/asan/host_check: tests/asan_host_check.cpp $(ASAN_OBJS) build/bn_kernel.hip.o build/io_kernels.hip.o
 	g++ $(ASAN_FLAGS) -o $@ $^ -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -ldl -lpthread
-asan: build/asan/host_check
+# ... and the command line's own host code (line cutter, block parser, packed-file writer), the same way, through
+# `FamSeq pack` (the mode that needs no GPU): TestData's full VCF six times over — blocks parsed on several threads —
+# and the probe file (every echo / drop / GL rule).
+build/asan/FamSeq: $(CSRC)/host/famseq_cli.cpp $(CSRC)/host/fmt_g6.h include/famseq_hip.h $(ASAN_OBJS) build/bn_kernel.hip.o build/io_kernels.hip.o
+	g++ $(ASAN_FLAGS) -I$(CSRC)/host -o $@ $(CSRC)/host/famseq_cli.cpp $(ASAN_OBJS) build/bn_kernel.hip.o build/io_kernels.hip.o \
+	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -ldl -lpthread
+asan: build/asan/host_check build/asan/FamSeq
 	ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 ./build/asan/host_check
+	@mkdir -p build/asan/tmp && zcat tests/golden/testdata/test_full.vcf.gz > build/asan/tmp/one.vcf && \
+	  (grep '^#' build/asan/tmp/one.vcf; for i in 1 2 3 4 5 6; do grep -v '^#' build/asan/tmp/one.vcf; done) > build/asan/tmp/six.vcf
+	ASAN_OPTIONS=detect_leaks=1 FAMSEQ_THREADS=5 ./build/asan/FamSeq pack -vcfFile build/asan/tmp/six.vcf -pedFile tests/golden/testdata/fam01.ped -output build/asan/tmp/six.fspl
+	ASAN_OPTIONS=detect_leaks=1 FAMSEQ_BATCH=7 ./build/asan/FamSeq pack -vcfFile tests/golden/testdata/probe.vcf -pedFile tests/golden/testdata/probe.ped -output build/asan/tmp/probe.fspl
 
 oracle:
 	$(MAKE) -C oracle all $(if $(wildcard /root/reference/src/family.cpp),ref,)
