@@ -551,17 +551,29 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "#define K2 ((W3 + 1) / 2)\n"
     // (every step's index is formed from the lane's own quotient/remainder and per-step constants,
     // not from the previous step's: a stepped index chains the LDS accesses one behind the other)
-    << "#define WALK8(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
-    << "  const int q0_ = t_ / W3, r0_ = t_ % W3; \\\n"
-    << "  _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { \\\n"
-    << "    const int rr_ = r0_ + (k * BT) % W3, c_ = rr_ >= W3; \\\n"
-    << "    const int e = t_ + k * BT, a = (q0_ + (k * BT) / W3 + c_) * ROW + rr_ - c_ * W3; { stmt; } } }\n"
-    << "#define WALK16(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
-    << "  const int q0_ = (2 * t_) / W3, r0_ = (2 * t_) % W3; \\\n"
-    << "  _Pragma(\"unroll\") for (int k = 0; k < K2; ++k) { if (k < W3 / 2 || t_ < BT / 2) { \\\n"
-    << "    const int rr_ = r0_ + (2 * k * BT) % W3, c_ = rr_ >= W3, r = rr_ - c_ * W3; \\\n"
-    << "    const int e = 2 * (t_ + k * BT), a = (q0_ + (2 * k * BT) / W3 + c_) * ROW + r; \\\n"
-    << "    const int a1 = r + 1 < W3 ? a + 1 : a + 1 + ROW - W3; stmt; } } }\n"
+    // The LDS index of chunk element e = q W3 + r is q ROW + r = e + q (ROW - W3).  With W3 odd and no spare
+    // slots ROW = W3 and the LDS image IS the global one (a = e: no quotient, no remainder — the general
+    // form's integer division, multiplications and selects, formed anew in every staging pass because the lane id is
+    // opaque, were a fifth of a five-member kernel's vector instructions, several of them quarter-rate);
+    // otherwise the quotient of the lane's first element, per-step constants and one carry per step.
+    << (ROW == W3
+            ? "#define WALK8(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
+              "  _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { const int e = t_ + k * BT, a = e; { stmt; } } }\n"
+              "#define WALK16(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
+              "  _Pragma(\"unroll\") for (int k = 0; k < K2; ++k) { if (k < W3 / 2 || t_ < BT / 2) { \\\n"
+              "    const int e = 2 * (t_ + k * BT), a = e, a1 = e + 1; stmt; } } }\n"
+            : "#define PAD (ROW - W3)\n"
+              "#define WALK8(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
+              "  const int q0_ = t_ / W3, r0_ = t_ - q0_ * W3, b0_ = t_ + q0_ * PAD; \\\n"
+              "  _Pragma(\"unroll\") for (int k = 0; k < W3; ++k) { \\\n"
+              "    const int c_ = r0_ + (k * BT) % W3 >= W3; \\\n"
+              "    const int e = t_ + k * BT, a = b0_ + (k * BT + (k * BT) / W3 * PAD) + (c_ ? PAD : 0); { stmt; } } }\n"
+              "#define WALK16(stmt) { int t_ = tid; asm volatile(\"\" : \"+v\"(t_)); \\\n"
+              "  const int q0_ = (2 * t_) / W3, r0_ = 2 * t_ - q0_ * W3, b0_ = 2 * t_ + q0_ * PAD; \\\n"
+              "  _Pragma(\"unroll\") for (int k = 0; k < K2; ++k) { if (k < W3 / 2 || t_ < BT / 2) { \\\n"
+              "    const int rr_ = r0_ + (2 * k * BT) % W3, c_ = rr_ >= W3, r = rr_ - (c_ ? W3 : 0); \\\n"
+              "    const int e = 2 * (t_ + k * BT), a = b0_ + (2 * k * BT + (2 * k * BT) / W3 * PAD) + (c_ ? PAD : 0); \\\n"
+              "    const int a1 = r + 1 < W3 ? a + 1 : a + 1 + PAD; stmt; } } }\n")
     << "#define TAIL(stmt) { for (int e = tid; e < nel; e += BT) { const int a = (e / W3) * ROW + e % W3; stmt; } }\n"
     // s_io <- G[site0 * W3 ...];  G[site0 * W3 ...] <- s_io;  pre <- next (whole) chunk;  s_io <- pre
     // (the outputs are written once and not read again here: non-temporal stores, +13 % on trios,
