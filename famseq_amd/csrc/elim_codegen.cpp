@@ -573,7 +573,8 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
               "  _Pragma(\"unroll\") for (int k = 0; k < K2; ++k) { if (k < W3 / 2 || t_ < BT / 2) { \\\n"
               "    const int rr_ = r0_ + (2 * k * BT) % W3, c_ = rr_ >= W3, r = rr_ - (c_ ? W3 : 0); \\\n"
               "    const int e = 2 * (t_ + k * BT), a = b0_ + (2 * k * BT + (2 * k * BT) / W3 * PAD) + (c_ ? PAD : 0); \\\n"
-              "    const int a1 = r + 1 < W3 ? a + 1 : a + 1 + PAD; stmt; } } }\n")
+              // (a pair starts at an even element: with W3 even its second element is in the same row)
+              "    const int a1 = (W3 % 2 == 0 || r + 1 < W3) ? a + 1 : a + 1 + PAD; (void)r; stmt; } } }\n")
     << "#define TAIL(stmt) { for (int e = tid; e < nel; e += BT) { const int a = (e / W3) * ROW + e % W3; stmt; } }\n"
     // s_io <- G[site0 * W3 ...];  G[site0 * W3 ...] <- s_io;  pre <- next (whole) chunk;  s_io <- pre
     // (the outputs are written once and not read again here: non-temporal stores, +13 % on trios,
