@@ -1376,7 +1376,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
     vector<std::string_view> lines;
     vector<Part> parts;
     int n_parts = 0;
-    size_t n_sites = 0;  // = lines of the block
+    size_t n_sites = 0;  // sites of the batch: the block's lines, or (large pedigrees) its sites moved together
     bool packed = true;
     vector<uint16_t> pk_pl;     // pack mode: the block's arrays live here, nothing is pinned
     vector<uint8_t> pk_flags;
@@ -1388,6 +1388,8 @@ bool run_vcf(const Options &o, const Ped &ped) {
   for (Slot &sl : slots) sl.parts.resize(n_threads), sl.text.resize(n_threads);
 
   double t_lines = 0, t_parse = 0, t_gather = 0, t_stall = 0, t_gpu = 0, t_format = 0, t_write = 0;
+  int compact_from = 12;  // members from which a block's sites are moved together before the GPU call (below)
+  if (const char *e = std::getenv("FAMSEQ_COMPACT_FROM")) compact_from = std::atoi(e);  // test aid
   Channel to_flusher, to_driver;
   std::atomic<bool> flush_ok{true};
   std::thread flusher([&] {
@@ -1538,12 +1540,36 @@ bool run_vcf(const Options &o, const Ped &ped) {
       to_driver.put(i);
       continue;
     }
+    // A line that is no site costs the GPU a site's work: nothing next to the text work for the usual pedigree, but
+    // 3^N configurations each.  From twelve members on (0.5 M configurations) the sites are moved together first —
+    // in place and in order, one thread: 60 bytes per site.
+    size_t n_real = 0;
+    for (int t = 0; t < sl.n_parts; ++t)
+      for (const Item &it : sl.parts[t].items) n_real += it.site >= 0;
+    if (n_real > 0 && n_real < nl && ped.n() >= compact_from) {
+      size_t d = 0;
+      for (int t = 0; t < sl.n_parts; ++t) {
+        Part &pt = sl.parts[t];
+        size_t x = 0;
+        for (Item &it : pt.items) {
+          if (it.site < 0) continue;
+          const size_t q = size_t(it.site);
+          if (d != q) {
+            flags_arr[d] = flags_arr[q];
+            std::memmove(pl_arr + d * 3 * n_seq, pl_arr + q * 3 * n_seq, 6 * n_seq);
+          }
+          if (x < pt.explicit_sites.size() && pt.explicit_sites[x] == q) pt.explicit_sites[x++] = uint32_t(d);
+          it.site = int32_t(d++);
+        }
+      }
+      sl.n_sites = d;
+    }
     if (!packed) {
       // fp64 rows: the table's value for every integer field (what the parser computed for it), the parsed rows of the others
-      sl.lk.resize(nl * N3);
+      const size_t n = sl.n_sites;
+      sl.lk.resize(n * N3);
       on_threads(sl.n_parts, [&](int t) {
-        const Part &pt = sl.parts[t];
-        const size_t lo = nl * t / sl.n_parts, hi = nl * (t + 1) / sl.n_parts;
+        const size_t lo = n * t / sl.n_parts, hi = n * (t + 1) / sl.n_parts;
         double *rows = sl.lk.data();
         std::fill(rows + lo * N3, rows + hi * N3, 1.0);
         for (size_t q = lo; q < hi; ++q)
@@ -1552,9 +1578,12 @@ bool run_vcf(const Options &o, const Ped &ped) {
             if (p[0] == 0xFFFF && p[1] == 0xFFFF && p[2] == 0xFFFF) continue;
             for (int g = 0; g < 3; ++g) rows[q * N3 + size_t(3) * seq_members[j] + g] = pl.value(p[g]);
           }
-        for (size_t x = 0; x < pt.explicit_sites.size(); ++x)
-          std::copy(&pt.explicit_lk[x * N3], &pt.explicit_lk[(x + 1) * N3], rows + size_t(pt.explicit_sites[x]) * N3);
       });
+      for (int t = 0; t < sl.n_parts; ++t) {
+        const Part &pt = sl.parts[t];
+        for (size_t x = 0; x < pt.explicit_sites.size(); ++x)
+          std::copy(&pt.explicit_lk[x * N3], &pt.explicit_lk[(x + 1) * N3], sl.lk.data() + size_t(pt.explicit_sites[x]) * N3);
+      }
     }
     t_gather += now_s() - t3;
     to_flusher.put(i);

@@ -286,3 +286,21 @@ def test_blocks_parsed_on_many_threads_give_the_single_thread_text(tmp_path):
     assert_same_output(serial, expect)
     n_warn = w1.count("Warning: this variant hasn't been calculated")
     assert n_warn == 2 and wn.count("Warning: this variant hasn't been calculated") == 200 * n_warn
+
+
+@pytest.mark.parametrize("batch", [None, "5"])
+def test_sites_moved_together_for_large_pedigrees(batch, tmp_path):
+    """From twelve members on the vcf driver compacts a block's sites before the GPU call (a line that is no site
+    would cost 3^N configurations as a dummy).  No TestData pedigree is that large: FAMSEQ_COMPACT_FROM=1 turns the
+    path on for the probe file (echo / drop / failure / chrX / missing-sample / GL lines between the sites, the GL
+    line taking the block through the fp64 rows) and for TestData's full VCF (12 sites among 9,861 lines)."""
+    env = dict(os.environ, FAMSEQ_COMPACT_FROM="1")
+    if batch:
+        env["FAMSEQ_BATCH"] = batch
+    for args, ref in ((["-vcfFile", TD + "/probe.vcf", "-pedFile", TD + "/probe.ped", "-a", "-mRate", "0"], REF + "/probe_mu0.vcf"),
+                      (["-vcfFile", TD + "/probe.vcf", "-pedFile", TD + "/probe.ped"], REF + "/probe_default.vcf"),
+                      (["-vcfFile", TD + "/test_subset.vcf", "-pedFile", TD + "/fam01.ped", "-a"], REF + "/subset_fam01_a.vcf")):
+        out = tmp_path / "o.vcf"
+        p = subprocess.run([CLI, "vcf"] + args + ["-output", str(out)], capture_output=True, text=True, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert assert_same_output(out, ref) > 0
