@@ -206,7 +206,7 @@ int load_elim(famseq_ctx *c) {
   if (!elim_supported(c->model, &why)) return fail(c, FAMSEQ_E_ARG, "elimination engine: " + why);
   try {
     const famseq_model &mdl = c->model;
-    const std::string src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v); }, kElimVariants, &c->elim_variant);
+    const std::string src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v); }, kElimVariants, &c->elim_variant, elim_first_variant(mdl));
     if (c->device < 0) {  // plan-only ctx: generate and compile into the cache (this is how build() pre-builds)
       c->elim.path = jit_compile(src);
       return 0;
@@ -242,7 +242,7 @@ bool load_lane(famseq_ctx *c, int d = 0) {
     if (hipSetDevice(c->device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
     k = jit_load(src, "famseq_enum_lane");
     int nb = 0;
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, enumgen_block_threads(c->model), 0) != hipSuccess)
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, enumgen_block_threads(c->model, d), 0) != hipSuccess)
       nb = 1;
     (d == 0 ? c->lane_blocks_per_cu : c->grp_blocks_per_cu[d]) = nb > 0 ? nb : 1;
     return true;
@@ -310,7 +310,7 @@ hipError_t launch_engine(famseq_ctx *c, int64_t n_sites, const double *d_lk, con
     if (load_lane(c, d)) {
       c->last_group_digits = d;
       if (d > 0)
-        return launch_generated(c, c->grp[d].fn, enumgen_block_threads(c->model), c->grp_blocks_per_cu[d], n_sites, d_lk,
+        return launch_generated(c, c->grp[d].fn, enumgen_block_threads(c->model, d), c->grp_blocks_per_cu[d], n_sites, d_lk,
                                 d_flags, d_post, d_single, d_status, stream, enumgen_sites_per_chunk(c->model, d));
       return launch_generated(c, c->lane.fn, enumgen_block_threads(c->model), c->lane_blocks_per_cu, n_sites, d_lk, d_flags,
                               d_post, d_single, d_status, stream);
@@ -333,7 +333,7 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
     const famseq_model &mdl = c->model;
     std::string src;
     if (elim) {
-      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants);
+      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants, nullptr, elim_first_variant(mdl));
     } else {
       // the same block size as the plain lane kernel runs with (variants 0-1 / 2-3: kEnumVariants), so that a batch
       // gives the same bits whether it goes through the fused kernel or through the separate stages

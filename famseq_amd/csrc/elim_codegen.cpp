@@ -373,10 +373,18 @@ int elim_conditioned_members(const famseq_model &m) {
   return build_graph(m, g, nullptr) ? (int)g.cut.size() : -1;
 }
 
-int elim_block_threads(const famseq_model &m) {
+// One-wave workgroups and no register cap, as for the enumeration kernel (enumgen_block_threads): 8 M five-member
+// sites 0.662 -> 0.617 ms, quads 0.507 -> 0.481.  Which variant runs best then depends on the pedigree's size: up to
+// eight members the fence-free one, at ONE wave per SIMD with its overflow in AGPRs (4 M sites: six members 0.459 ->
+// 0.403 ms, seven 0.570 -> 0.512, eight 0.718 -> 0.607; two-family pedigrees of seven and eight members likewise);
+// from nine on the first fenced one, which fits two waves per SIMD (ten members 0.664 -> 0.640, fifteen 1.118 -> 1.047,
+// where the fence-free one at one wave took 0.723 and 1.076): profiles/r02c/exp_elim_waves*.txt.
+int elim_block_threads(const famseq_model &) {
   if (const char *e = std::getenv("FAMSEQ_ELIM_BT")) return std::atoi(e);  // tuning aid
-  return m.n_members <= 10 ? 256 : 128;
+  return 64;
 }
+
+int elim_first_variant(const famseq_model &m) { return m.n_members >= 9 ? 1 : 0; }
 
 // Text every generated kernel carries for the fused call path (SURVEY.md 8(f) rows N2 + N4): packed
 // integer PLs staged straight into the LDS rows (the reference's lk = pow(10, -|PL| / 10), file.cpp:588-590,
@@ -727,7 +735,7 @@ std::string elim_source(const famseq_model &m, int variant, bool call_mode) {
   std::string why;
   if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);
   const int bt = elim_block_threads(m);
-  int min_waves = m.n_members <= 10 ? 2 : 1;
+  int min_waves = 1;
   if (const char *e = std::getenv("FAMSEQ_ELIM_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
   // From variant 1 on the transmission tables are read through scalar loads (measured: +9 % at 10
   // members where registers are tight, -7 % on the fence-free 5-member kernel, which keeps the LDS table).

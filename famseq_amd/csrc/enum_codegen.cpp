@@ -700,8 +700,16 @@ std::string enumgen_describe(const famseq_model &m, int variant) {
   return d + "] = " + num(n) + " configurations per step";
 }
 
-int enumgen_block_threads(const famseq_model &m) {
+// One lane per site: workgroups of ONE wave, and no register cap (`__launch_bounds__(64, 1)`).  A wave that
+// shares its workgroup with nobody waits at no real barrier, so the waves of a CU drift apart and one's memory phases
+// overlap another's arithmetic (five members 0.724 -> 0.683 ms per 8 M sites, quads 0.570 -> 0.537); and where the
+// arithmetic needs more than 256 registers the compiler now takes one wave per SIMD with its overflow in AGPRs —
+// the ten-member kernel: 24 of them instead of 108 bytes of scratch per lane, an LDS row of 43 instead of 37 doubles
+// (a quarter of the lanes per CU: no likelihood is re-read from global memory any more), 10.21 -> 9.78 ms per 4 M sites
+// (profiles/r02c/exp_block_sizes_*.txt).  The lanes-per-site forms keep wide workgroups: a site's 81 lanes span waves.
+int enumgen_block_threads(const famseq_model &m, int group_digits) {
   if (const char *e = std::getenv("FAMSEQ_LANE_BT")) return std::atoi(e);  // tuning aid
+  if (group_digits == 0) return 64;
   return m.n_members <= 10 ? 256 : 128;
 }
 
@@ -720,7 +728,7 @@ int enumgen_max_group_digits(const famseq_model &m) {
 int enumgen_sites_per_chunk(const famseq_model &m, int group_digits) {
   int g = 1;
   for (int k = 0; k < group_digits; ++k) g *= 3;
-  return enumgen_block_threads(m) / g;
+  return enumgen_block_threads(m, group_digits) / g;
 }
 
 namespace {
@@ -810,7 +818,7 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
   if (s.unrolled.empty()) throw std::runtime_error("enumeration codegen: empty unrolled set");
   if (group_digits < 0 || group_digits > std::min<int>(kEnumMaxGroupDigits, (int)s.outer.size()))
     throw std::runtime_error("enumeration codegen: more group digits than looped members");
-  const int bt = enumgen_block_threads(m);
+  const int bt = enumgen_block_threads(m, group_digits);
   // The lane's LDS row: 3N doubles padded to an odd count, plus — while two workgroups per CU still
   // fit in the 160 KB — room for the likelihoods of unrolled members whose tables are rebuilt inside
   // the loops (otherwise re-read from global memory there: L2 misses that show up as HBM traffic).
@@ -856,7 +864,7 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
     what = "3^N enumeration, " + std::to_string(group) + " lanes per site (" + std::to_string(group_digits) + " of " +
            std::to_string(s.outer.size()) + " looped members' digits on lanes), " + std::to_string(s.unrolled.size()) +
            " unrolled members, variant " + std::to_string(variant);
-  int min_waves = bt / 128;
+  int min_waves = group_digits == 0 ? 1 : bt / 128;
   if (const char *e = std::getenv("FAMSEQ_LANE_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
   Gen gen(m, s, late ? std::max(scratch_len, 1) : row_len, group_digits, late);
   if (call_mode) what += ", call path";

@@ -25,7 +25,7 @@ int enumgen_max_group_digits(const famseq_model &m);
 // must be given fp64 input (lk_g non-null), never packed PLs
 bool enumgen_reads_global_rows(const famseq_model &m, int variant);
 int enumgen_sites_per_chunk(const famseq_model &m, int group_digits);  // sites a workgroup handles per chunk
-int enumgen_block_threads(const famseq_model &m);
+int enumgen_block_threads(const famseq_model &m, int group_digits = 0);
 // One-line description of the lane kernel's tiling (which members are looped / unrolled).
 std::string enumgen_describe(const famseq_model &m, int variant = -1);  // shape of the one-lane-per-site kernel of that variant
 

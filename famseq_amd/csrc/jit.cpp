@@ -278,10 +278,10 @@ std::string jit_compile(const std::string &source, int *scratch_bytes, bool note
 // scratch on the fence-free 5-member sum-product kernel, still 7 % faster than the fenced one).
 constexpr int kSpillTolerance = 16;  // bytes per lane
 
-std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked) {
+std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked, int first) {
   std::string best;
   int best_scratch = -1, best_i = 0;
-  int first = 0;
+  first = std::max(0, std::min(first, n_variants - 1));
   if (const char *e = std::getenv("FAMSEQ_VARIANT_MIN")) first = std::max(0, std::min(std::atoi(e), n_variants - 1));  // tuning aid
   std::vector<std::string> rejected;  // code objects of variants that lost: only their resource notes are kept
   std::string best_obj;

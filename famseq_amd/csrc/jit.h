@@ -34,7 +34,7 @@ std::string jit_compile(const std::string &source, int *scratch_bytes = nullptr,
 // The generators can trade instruction-level parallelism against register pressure
 // (`variant` 0 = most parallel).  Compiles variants in order and returns the source of the
 // first one that does not spill (more than 16 bytes per lane), or of the one that spills least.  *picked = its index.
-std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked = nullptr);
+std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked = nullptr, int first = 0);
 void jit_unload(JitKernel &k);
 
 }  // namespace famseq

@@ -89,6 +89,9 @@ PED15 = PED5 + [(6, 0, 0, 2), (7, 0, 0, 1), (8, 0, 0, 2), (9, 6, 3, 1), (10, 6, 
 def synthetic_pedigree(name) -> Pedigree:
     """ped5 / ped10 / ped15 are BASELINE.json's benchmark pedigrees; trio and quad (the first 3 and 4
     members of ped5) are the shapes most real callers have; sibN = two parents and N - 2 children (tuning aid)."""
+    if ":" in name:  # "ped10:8" = the first 8 members of ped10 (tuning aid; the prefix must be closed under parents)
+        base, k = name.split(":")
+        return _mk({"ped5": PED5, "ped10": PED10, "ped15": PED15}[base][:int(k)])
     if name.startswith("sib"):
         return _mk([(1, 0, 0, 1), (2, 0, 0, 2)] + [(3 + i, 2, 1, 1 + i % 2) for i in range(int(name[3:]) - 2)])
     return _mk({"trio": PED5[:3], "quad": PED5[:4], "ped5": PED5, "ped10": PED10, "ped15": PED15}[name])

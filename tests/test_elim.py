@@ -64,7 +64,9 @@ def test_too_many_loops_stay_on_enumeration():
 
 def test_variant_is_the_first_that_does_not_spill(tmp_path, monkeypatch):
     """The generators emit variants from most to least instruction-level parallelism; the JIT takes
-    the first one hipcc reports spill-free and leaves that report next to each code object.
+    the first one the compiler reports spill-free and leaves that report next to each code object.  With one-wave
+    workgroups and no register cap nothing spills to scratch, and where to start is a measured rule
+    (elim_first_variant: the fence-free variant up to eight members, the first fenced one from nine on).
     (A fresh cache directory: every candidate is really compiled here.)"""
     monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
     picked = {}
@@ -77,7 +79,22 @@ def test_variant_is_the_first_that_does_not_spill(tmp_path, monkeypatch):
         obj = p["elim_code_object"]
         assert obj.startswith(str(tmp_path))
         assert int(open(obj[:-6] + ".res").read()) == 0  # the variant in use has no scratch
+    assert picked == {"ped5": 0, "ped10": 1}
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".res")]) == 2  # nothing else was compiled
+
+
+def test_a_spilling_variant_is_passed_over(tmp_path, monkeypatch):
+    """The picker's own rule, on the form that does spill: 256-lane workgroups at two waves per SIMD (256 registers)
+    from variant 0 — the ten-member fence-free variant is compiled, reports scratch, and loses to the next."""
+    monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
+    monkeypatch.setenv("FAMSEQ_ELIM_BT", "256")
+    monkeypatch.setenv("FAMSEQ_ELIM_MINWAVES", "2")
+    monkeypatch.setenv("FAMSEQ_VARIANT_MIN", "0")
+    ctx = fs.Context(fs.make_model(fs.synthetic_pedigree("ped10")), device=-1)
+    ctx.set_option("engine", fs.ENGINE_ELIM)
+    p = ctx.plan()
+    ctx.close()
     notes = sorted(int(open(os.path.join(tmp_path, f)).read()) for f in os.listdir(tmp_path) if f.endswith(".res"))
-    assert picked["ped5"] == 0                      # small pedigree: fence-free fits
-    assert picked["ped10"] >= 1 and notes[-1] > 0   # wider one: variant 0 was compiled, spilled, and was passed over
-    assert len(notes) == 1 + picked["ped10"] + 1
+    assert p["elim_variant"] >= 1 and notes[0] == 0 and notes[-1] > 0
+    assert len(notes) == p["elim_variant"] + 1
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 1  # the loser keeps its note only

@@ -394,19 +394,28 @@ def test_packed_input_is_refused_to_a_kernel_that_rereads_fp64_rows(tmp_path, mo
     monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
     monkeypatch.setenv("FAMSEQ_KEEP_SRC", "1")
     monkeypatch.setenv("FAMSEQ_JIT_SOURCE_ONLY", "1")
-    monkeypatch.setenv("FAMSEQ_LANE_CAP", "6")  # the 6-member block: the form these pedigrees run in (the 7-member one spills)
-    seen = set()
-    for seed in (2, 8, 10):
-        _, ped, mu = soak_pedigree(seed)
-        ctx = fs.Context(fs.make_model(ped, mrate=mu), device=-1)
-        ctx.set_option("enum_impl", 1)
-        ctx.set_option("call_kernels", 1)
-        plan = ctx.plan()
-        ctx.close()
-        call_src = open(plan["enum_lane_call_code_object"][:-6] + ".hip").read()
-        assert plan["enum_lane_call_reads_rows"] == int("lg[" in call_src), seed
-        seen.add(plan["enum_lane_call_reads_rows"])
-    assert seen == {0, 1}
+    monkeypatch.setenv("FAMSEQ_LANE_CAP", "6")  # the 6-member block: the form these pedigrees ran in (the 7-member one spilled)
+
+    def rereads(bt):
+        if bt:
+            monkeypatch.setenv("FAMSEQ_LANE_BT", bt)
+        seen = set()
+        for seed in (2, 8, 10):
+            _, ped, mu = soak_pedigree(seed)
+            ctx = fs.Context(fs.make_model(ped, mrate=mu), device=-1)
+            ctx.set_option("enum_impl", 1)
+            ctx.set_option("call_kernels", 1)
+            plan = ctx.plan()
+            ctx.close()
+            call_src = open(plan["enum_lane_call_code_object"][:-6] + ".hip").read()
+            assert plan["enum_lane_call_reads_rows"] == int("lg[" in call_src), seed
+            seen.add(plan["enum_lane_call_reads_rows"])
+        return seen
+
+    # one-wave workgroups (the default since round 2's last third): a quarter of the lanes per CU, so the LDS row
+    # always has room and nothing is re-read; the 256-lane form these pedigrees ran in is the one with both answers
+    assert rereads(None) == {0}
+    assert rereads("256") == {0, 1}
 
 
 def _threaded_call_kernel(model, elim, bt, cache, monkeypatch):
