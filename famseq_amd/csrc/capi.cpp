@@ -333,7 +333,7 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
     const famseq_model &mdl = c->model;
     std::string src;
     if (elim) {
-      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants, nullptr, elim_first_variant(mdl));
+      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants, nullptr, elim_first_variant(mdl, true));
     } else {
       // the same block size as the plain lane kernel runs with (variants 0-1 / 2-3: kEnumVariants), so that a batch
       // gives the same bits whether it goes through the fused kernel or through the separate stages
@@ -351,7 +351,7 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
     if (hipSetDevice(c->device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
     k = jit_load(src, elim ? "famseq_elim" : "famseq_enum_lane");
     int nb = 0;
-    const int bt = elim ? elim_block_threads(c->model) : enumgen_block_threads(c->model);
+    const int bt = elim ? elim_block_threads(c->model, true) : enumgen_block_threads(c->model);
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, bt, 0) != hipSuccess) nb = 1;
     (elim ? c->elim_call_blocks_per_cu : c->lane_call_blocks_per_cu) = nb > 0 ? nb : 1;
     return true;
@@ -376,7 +376,7 @@ bool launch_engine_fused(famseq_ctx *c, int64_t n_sites, const double *d_lk, con
   if (!load_call_kernel(c, elim)) return false;
   if (!elim && packed_in && c->lane_reads_rows != 0) return false;  // (set by load_call_kernel for the variant it took)
   if (!elim) c->last_group_digits = 0;
-  *err = launch_generated(c, elim ? c->elim_call.fn : c->lane_call.fn, elim ? elim_block_threads(c->model) : enumgen_block_threads(c->model),
+  *err = launch_generated(c, elim ? c->elim_call.fn : c->lane_call.fn, elim ? elim_block_threads(c->model, true) : enumgen_block_threads(c->model),
                           elim ? c->elim_call_blocks_per_cu : c->lane_call_blocks_per_cu, n_sites, d_lk, d_flags, nullptr, nullptr,
                           d_status, stream, 0, d_io);
   return true;

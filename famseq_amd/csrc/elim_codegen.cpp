@@ -379,12 +379,16 @@ int elim_conditioned_members(const famseq_model &m) {
 // 0.403 ms, seven 0.570 -> 0.512, eight 0.718 -> 0.607; two-family pedigrees of seven and eight members likewise);
 // from nine on the first fenced one, which fits two waves per SIMD (ten members 0.664 -> 0.640, fifteen 1.118 -> 1.047,
 // where the fence-free one at one wave took 0.723 and 1.076): profiles/r02c/exp_elim_waves*.txt.
-int elim_block_threads(const famseq_model &) {
+// The fused call-path form is another kernel — paced by the sixty logarithms per site between its barriers, not by
+// memory — and keeps 256-lane workgroups at two waves per SIMD: 0.317 ms per 1 M ten-member sites against 0.487 in
+// one-wave workgroups (tools/call_ab.sh).
+int elim_block_threads(const famseq_model &m, bool call_mode) {
   if (const char *e = std::getenv("FAMSEQ_ELIM_BT")) return std::atoi(e);  // tuning aid
+  if (call_mode) return m.n_members <= 10 ? 256 : 128;
   return 64;
 }
 
-int elim_first_variant(const famseq_model &m) { return m.n_members >= 9 ? 1 : 0; }
+int elim_first_variant(const famseq_model &m, bool call_mode) { return !call_mode && m.n_members >= 9 ? 1 : 0; }
 
 // Text every generated kernel carries for the fused call path (SURVEY.md 8(f) rows N2 + N4): packed
 // integer PLs staged straight into the LDS rows (the reference's lk = pow(10, -|PL| / 10), file.cpp:588-590,
@@ -734,8 +738,8 @@ std::string elim_source(const famseq_model &m, int variant, bool call_mode) {
   Graph g;
   std::string why;
   if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);
-  const int bt = elim_block_threads(m);
-  int min_waves = 1;
+  const int bt = elim_block_threads(m, call_mode);
+  int min_waves = call_mode && m.n_members <= 10 ? 2 : 1;
   if (const char *e = std::getenv("FAMSEQ_ELIM_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
   // From variant 1 on the transmission tables are read through scalar loads (measured: +9 % at 10
   // members where registers are tight, -7 % on the fence-free 5-member kernel, which keeps the LDS table).

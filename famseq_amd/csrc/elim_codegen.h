@@ -19,8 +19,8 @@ int elim_conditioned_members(const famseq_model &m);
 constexpr int kElimVariants = 4;
 // call_mode: the fused call path's form (packed PLs or fp64 rows in; GPP / FPP / FGT / status out)
 std::string elim_source(const famseq_model &m, int variant, bool call_mode = false);
-int elim_block_threads(const famseq_model &m);
-int elim_first_variant(const famseq_model &m);  // where jit_pick_variant starts (see elim_block_threads)
+int elim_block_threads(const famseq_model &m, bool call_mode = false);
+int elim_first_variant(const famseq_model &m, bool call_mode = false);  // where jit_pick_variant starts (see elim_block_threads)
 
 // Shared shell of the generated kernels (see elim_codegen.cpp).
 extern const std::string kCallHelpers;  // fused call path: fs_phred, STAGE_IN_PL, STAGE_OUT_CALL, STAGE_FGT

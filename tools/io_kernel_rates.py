@@ -9,13 +9,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import famseq_amd as fs
 
-ped = fs.synthetic_pedigree("ped10")
+ped = fs.synthetic_pedigree(sys.argv[3] if len(sys.argv) > 3 else "ped10")
 n_sites = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 rng = np.random.RandomState(1)
 pl = rng.randint(0, 400, size=(n_sites, ped.n, 3)).astype(np.uint16)
 pl[np.arange(n_sites), :, rng.randint(0, 3, n_sites)] = 0
 ctx = fs.Context(fs.make_model(ped))
-ctx.set_option("engine", fs.ENGINE_ELIM)
+if not (len(sys.argv) > 2 and sys.argv[2] == "enum"):  # default: the sum-product engine's call-path form
+    ctx.set_option("engine", fs.ENGINE_ELIM)
 ctx.set_option("chunk_sites", 1 << 20)
 seq = np.arange(ped.n, dtype=np.int32)
 for _ in range(3):
