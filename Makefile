@@ -34,7 +34,7 @@ $(LIB): $(OBJS) build/stub/libamdhip64.so
 	    -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags -ldl -lpthread
 
 # FamSeq-compatible command line (host C++ only; talks to the GPU through the C ABI)
-$(CLI): $(CSRC)/host/famseq_cli.cpp include/famseq_hip.h $(LIB)
+$(CLI): $(CSRC)/host/famseq_cli.cpp $(CSRC)/host/fmt_g6.h include/famseq_hip.h $(LIB)
 	@mkdir -p bin
 	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ $(CSRC)/host/famseq_cli.cpp -Lfamseq_amd/lib -lfamseq_hip -lpthread \
 	    -Wl,-rpath,'$$ORIGIN/../famseq_amd/lib' -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
