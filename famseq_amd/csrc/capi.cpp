@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -93,6 +94,7 @@ struct famseq_ctx {
   int32_t *d_seq = nullptr, *d_col = nullptr;
   CallIO *d_call[kSlots] = {};  // the generated kernels' call-path arguments, one per slot
   std::vector<int32_t> seq_members;
+  std::string tune_report;  // what famseq_set_option "tune" measured (famseq_plan_json "tune")
   std::string err, json;
 };
 
@@ -206,7 +208,10 @@ int load_elim(famseq_ctx *c) {
   if (!elim_supported(c->model, &why)) return fail(c, FAMSEQ_E_ARG, "elimination engine: " + why);
   try {
     const famseq_model &mdl = c->model;
-    const std::string src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v); }, kElimVariants, &c->elim_variant, elim_first_variant(mdl));
+    int first = elim_first_variant(mdl);
+    const int pick = jit_read_pick(elim_source(mdl, 0));  // the autotuner's note, where this pedigree has been tuned here
+    if (pick >= 0 && pick < kElimVariants) first = pick;
+    const std::string src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v); }, kElimVariants, &c->elim_variant, first);
     if (c->device < 0) {  // plan-only ctx: generate and compile into the cache (this is how build() pre-builds)
       c->elim.path = jit_compile(src);
       return 0;
@@ -232,8 +237,12 @@ bool load_lane(famseq_ctx *c, int d = 0) {
   if (c->device < 0 && !k.path.empty()) return true;
   try {
     const famseq_model &mdl = c->model;
-    int variant = -1;
-    const std::string src = jit_pick_variant([&mdl, d](int v) { return enumgen_source(mdl, v, d); }, kEnumVariants, &variant);
+    int variant = -1, first = 0;
+    if (d == 0) {
+      const int pick = jit_read_pick(enumgen_source(mdl, 0, 0));  // the autotuner's note (7- or 6-member block)
+      if (pick >= 0 && pick < kEnumVariants) first = pick;
+    }
+    const std::string src = jit_pick_variant([&mdl, d](int v) { return enumgen_source(mdl, v, d); }, kEnumVariants, &variant, first);
     if (d == 0) c->lane_variant = variant;
     if (c->device < 0) {
       k.path = jit_compile(src);
@@ -476,6 +485,131 @@ extern "C" void famseq_destroy(famseq_ctx *c) {
 
 extern "C" const char *famseq_last_error(famseq_ctx *c) { return c ? c->err.c_str() : "ctx is NULL"; }
 
+namespace {
+
+// famseq_set_option(ctx, "tune", 1): where static rules pick a generated kernel's variant (the sum-product kernel's
+// fence variant by pedigree size, the enumeration kernel's 7- or 6-member block), time the candidates on THIS device
+// and pedigree — synthetic rows, a few milliseconds each — and leave the winner's index as a note in the kernel
+// cache; every later context for the pedigree starts from it.  Opt-in: it compiles every candidate.
+int tune(famseq_ctx *c) {
+  if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "tuning times kernels: it needs a device");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const famseq_model &mdl = c->model;
+  const int N = mdl.n_members;
+  // about 10 ms of enumeration per launch, 64 K - 2 M sites; the sum-product kernel, whose time does not grow with
+  // 3^N, always gets the 2 M (at 64 K sites its launch is most of what a timer sees)
+  const double want = 0.01 * 2.4e13 / std::pow(3.0, N);
+  const int64_t n_enum = std::max<int64_t>(1 << 16, std::min<int64_t>(int64_t(1) << 21, (int64_t)want)) / 64 * 64;
+  const int64_t n_elim = int64_t(1) << 21, n_max = std::max(n_enum, n_elim);
+  int64_t n = n_enum;  // sites of the launches being timed
+  const size_t w = size_t(n_max) * 3 * N;
+  double *d_lk = nullptr, *d_post = nullptr, *d_single = nullptr;
+  uint8_t *d_status = nullptr;
+  auto release = [&] {
+    for (void *q : {(void *)d_lk, (void *)d_post, (void *)d_single, (void *)d_status})
+      if (q) (void)hipFree(q);
+  };
+  if (hipMalloc(reinterpret_cast<void **>(&d_lk), w * 8) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_post), w * 8) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&d_single), w * 8) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_status), size_t(n_max)) != hipSuccess) {
+    release();
+    return fail(c, FAMSEQ_E_HIP, "tune: device buffers");
+  }
+  {
+    std::vector<double> h(w);
+    uint64_t z = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < w; i += 3) {  // PL-shaped rows: one genotype at 1, the others 10^-(k/10)
+      z = z * 6364136223846793005ull + 1442695040888963407ull;
+      const unsigned a = unsigned(z >> 33) % 3, p1 = 3 + unsigned(z >> 40) % 88, p2 = p1 + unsigned(z >> 50) % 160;
+      h[i + a] = 1.0, h[i + (a + 1) % 3] = std::pow(10.0, -0.1 * p1), h[i + (a + 2) % 3] = std::pow(10.0, -0.1 * p2);
+    }
+    if (hipMemcpy(d_lk, h.data(), w * 8, hipMemcpyHostToDevice) != hipSuccess) {
+      release();
+      return fail(c, FAMSEQ_E_HIP, "tune: upload");
+    }
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  std::string report;
+  // best of three launches of one candidate, ms (< 0: it could not be built)
+  auto time_one = [&](const std::string &src, const char *entry, int bt) {
+    JitKernel k;
+    try {
+      k = jit_load(src, entry);
+    } catch (const std::exception &) {
+      return -1.0;
+    }
+    int nb = 1;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, bt, 0) != hipSuccess || nb < 1) nb = 1;
+    double best = -1;
+    for (int rep = 0; rep < 4; ++rep) {
+      (void)hipEventRecord(e0, c->stream[1]);
+      const hipError_t e = launch_generated(c, k.fn, bt, nb, n, d_lk, nullptr, d_post, d_single, d_status, c->stream[1]);
+      (void)hipEventRecord(e1, c->stream[1]);
+      if (e != hipSuccess || hipEventSynchronize(e1) != hipSuccess) {
+        best = -1;
+        break;
+      }
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (rep > 0 && (best < 0 || ms < best)) best = ms;  // the first launch warms up
+    }
+    jit_unload(k);
+    return best;
+  };
+  auto race = [&](const char *what, const std::vector<int> &cands, const std::function<std::string(int)> &gen, const char *entry, int bt) {
+    int win = -1;
+    double win_ms = 0;
+    report += std::string(report.empty() ? "" : "; ") + what + ":";
+    for (int v : cands) {
+      const double ms = time_one(gen(v), entry, bt);
+      char buf[64];
+      std::snprintf(buf, sizeof buf, " v%d %.4f ms", v, ms);
+      report += buf;
+      if (ms > 0 && (win < 0 || ms < win_ms * 0.99)) win = v, win_ms = ms;  // a later candidate has to win by 1 %
+    }
+    if (win >= 0) {
+      jit_write_pick(gen(0), win);
+      report += " -> v" + std::to_string(win);
+    }
+    return win;
+  };
+  try {
+    if (enumgen_describe(mdl, 0) != enumgen_describe(mdl, 2))
+      (void)race("enumeration (7- / 6-member block)", {0, 2}, [&mdl](int v) { return enumgen_source(mdl, v, 0); }, "famseq_enum_lane",
+                 enumgen_block_threads(mdl, 0));
+    else
+      report += "enumeration: one block shape, nothing to choose";
+    n = n_elim;
+    if (elim_supported(mdl, nullptr))
+      (void)race("sum-product (fence variants)", {0, 1}, [&mdl](int v) { return elim_source(mdl, v); }, "famseq_elim", elim_block_threads(mdl));
+  } catch (const std::exception &e) {
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    release();
+    return fail(c, FAMSEQ_E_HIP, std::string("tune: ") + e.what());
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  release();
+  c->tune_report = report + " (synthetic sites per launch: " + std::to_string(n_enum) + " enumeration, " + std::to_string(n_elim) + " sum-product)";
+  // the kernels this context holds may have lost: drop them, the next use loads the picks
+  const bool had_lane = c->lane.fn != nullptr, had_elim = c->elim.fn != nullptr, had_lc = c->lane_call.fn != nullptr;
+  jit_unload(c->lane), jit_unload(c->lane_call), jit_unload(c->elim);
+  c->lane.path.clear(), c->lane_call.path.clear(), c->elim.path.clear();
+  c->lane_variant = c->lane_call_variant = c->elim_variant = -1;
+  c->lane_reads_rows = -1;
+  if (had_lane && !load_lane(c)) return fail(c, FAMSEQ_E_HIP, "lane kernel unavailable after tuning: " + c->lane_error);
+  if (had_lc && !load_call_kernel(c, false)) return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable after tuning: " + c->lane_error);
+  if (had_elim || c->engine == FAMSEQ_ENGINE_ELIM) {
+    const int rc = load_elim(c);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+}  // namespace
+
 extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) {
   if (!c || !key) return FAMSEQ_E_ARG;
   const std::string k(key);
@@ -491,6 +625,10 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
     return 0;
   }
   else if (k == "lane_min_sites") { c->lane_min_sites = value; return 0; }
+  else if (k == "tune") {
+    if (value != 1) return fail(c, FAMSEQ_E_ARG, "tune takes 1");
+    return tune(c);
+  }
   else if (k == "call_kernels") {  // build (and on a device ctx load) the fused call-path forms now rather than on first use
     if (value != 1) return fail(c, FAMSEQ_E_ARG, "call_kernels takes 1");
     if (!load_call_kernel(c, false)) return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable: " + c->lane_error);
@@ -563,7 +701,8 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
              std::to_string(c->last_group_digits) + ",\"enum_group_code_objects\":[";
   for (int d = 1; d <= kEnumMaxGroupDigits; ++d) c->json += std::string(d > 1 ? "," : "") + "\"" + json_str(c->grp[d].path) + "\"";
   c->json += "],\"enum_lane_call_code_object\":\"" + json_str(c->lane_call.path) + "\",\"elim_call_code_object\":\"" +
-             json_str(c->elim_call.path) + "\",\"enum_lane_call_reads_rows\":" + std::to_string(c->lane_reads_rows) + "}";
+             json_str(c->elim_call.path) + "\",\"enum_lane_call_reads_rows\":" + std::to_string(c->lane_reads_rows) + ",\"tune\":\"" +
+             json_str(c->tune_report) + "\"}";
   return c->json.c_str();
 }
 

@@ -157,6 +157,7 @@ void parallel_for(size_t n, F f) {
 struct Options {
   bool lk_mode = false;
   bool pack_mode = false;  // `FamSeq pack`: vcf -> packed binary PL file (no GPU)
+  bool tune_mode = false;  // `FamSeq tune`: time this pedigree's kernel variants on this GPU, keep the winners' indices in the kernel cache
   bool pl_mode = false;    // `FamSeq PL`: packed binary PL file -> calls
   bool unpack_mode = false;  // `FamSeq unpack`: packed PL file + packed result file -> the text `FamSeq PL` writes
   bool bin_output = false;   // `FamSeq PL -binOutput`: results as a packed result file, not as text
@@ -329,7 +330,7 @@ int parse_options(int argc, char **argv, Options &o) {
     std::cout << "The name of ped file must be set. Please input the ped file name." << std::endl;
     return -1;
   }
-  if (o.out_file.empty()) {
+  if (o.out_file.empty() && !o.tune_mode) {
     std::cout << "The name of output file must be set. Please input the output file name." << std::endl;
     return -1;
   }
@@ -1678,6 +1679,36 @@ bool run_lk(const Options &o, const Ped &ped) {
   return ok;
 }
 
+// ---- `FamSeq tune -vcfFile f -pedFile p`: the generated kernels depend on the pedigree and on which of its members the
+// vcf file has columns for; time their variants on this GPU (famseq_set_option "tune") and leave the picks in the cache.
+bool run_tune(const Options &o, const Ped &ped) {
+  LineSource fin;
+  if (!fin.open(o.vcf_files[0])) {
+    std::cout << "Cannot open " << o.vcf_files[0] << std::endl;
+    return false;
+  }
+  std::string_view line;
+  string title;
+  while (fin.next(line) && !line.empty() && line[0] == '#') title.assign(line);
+  const vector<string> head = split_keep(title, '\t');
+  vector<uint8_t> sequenced(ped.n(), 0);
+  for (size_t i = 9; i < head.size(); i++)
+    for (int j = 0; j < ped.n(); j++)
+      if (head[i] == ped.name[j]) sequenced[j] = 1;
+  famseq_model m;
+  famseq_ctx *ctx = make_ctx(o, ped, sequenced, m);
+  if (!ctx) return false;
+  const int rc = famseq_set_option(ctx, "tune", 1);
+  if (rc != 0) std::cout << "Tuning failed: " << famseq_last_error(ctx) << std::endl;
+  else {
+    const string plan = famseq_plan_json(ctx);
+    const size_t k = plan.find("\"tune\":\"");
+    std::cout << (k == string::npos ? plan : plan.substr(k + 8, plan.size() - k - 10)) << std::endl;
+  }
+  famseq_destroy(ctx);
+  return rc == 0;
+}
+
 void usage_top() {
   std::cout << std::endl
             << "Program: FamSeq (Sequence calling using pedigree information), MI355X build of the -method 1 path"
@@ -1709,6 +1740,8 @@ void help() {
             << "PL\t\tFamSeq PL -plFile f.fspl -pedFile p -output o [-binOutput]: call variants from a packed PL file" << std::endl
             << "\t\t(-binOutput: write a packed result file instead of text)." << std::endl
             << "unpack\t\tFamSeq unpack -plFile f.fspl -poFile r.fspo -pedFile p -output o: the text of a packed result file." << std::endl
+            << "tune\t\tFamSeq tune -vcfFile f -pedFile p: time this pedigree's kernel variants on this GPU once and keep the" << std::endl
+            << "\t\tfaster ones' indices in the kernel cache (later runs start from them)." << std::endl
             << "Environment: FAMSEQ_DEVICE (GPU index, default 0), FAMSEQ_BATCH (sites per GPU batch)." << std::endl;
 }
 
@@ -1724,9 +1757,9 @@ int main(int argc, char **argv) {
     help();
     return 0;
   }
-  if (mode != "vcf" && mode != "LK" && mode != "pack" && mode != "PL" && mode != "unpack") {
+  if (mode != "vcf" && mode != "LK" && mode != "pack" && mode != "PL" && mode != "unpack" && mode != "tune") {
     std::cout << "Cannot recognize the input type: \"" << argv[1] << "\"." << std::endl
-              << "The input type can only be vcf or LK (or pack / PL / unpack for the packed binary formats)" << std::endl << std::endl
+              << "The input type can only be vcf or LK (or pack / PL / unpack for the packed binary formats, or tune)" << std::endl << std::endl
               << "Type FamSeq -h for help." << std::endl;
     return -1;
   }
@@ -1740,6 +1773,7 @@ int main(int argc, char **argv) {
   o.pl_mode = mode == "PL" || mode == "unpack";
   o.unpack_mode = mode == "unpack";
   o.pack_mode = mode == "pack";
+  o.tune_mode = mode == "tune";
   const int rc = parse_options(argc, argv, o);
   if (rc < 0) return -1;
   if (rc > 0)
@@ -1756,6 +1790,7 @@ int main(int argc, char **argv) {
     return -1;
   }
   const double t0 = now_s();
+  if (o.tune_mode) return run_tune(o, ped) ? 0 : -1;
   const bool ok = o.pl_mode ? run_pl(o, ped) : (o.lk_mode ? run_lk(o, ped) : run_vcf(o, ped));
   if (std::getenv("FAMSEQ_TIMING")) std::cerr << "FamSeq " << mode << ": " << now_s() - t0 << " s in the driver" << std::endl;
   return ok ? 0 : -1;

@@ -309,6 +309,40 @@ std::string jit_pick_variant(const std::function<std::string(int)> &generate, in
   return best;
 }
 
+namespace {
+std::string pick_name(const std::string &key_source) {
+  char name[40];
+  std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(key_source + kCompilerTag));
+  return std::string(name) + ".pick";
+}
+}  // namespace
+
+int jit_read_pick(const std::string &key_source) {
+  const std::string name = pick_name(key_source);
+  std::vector<std::string> dirs;
+  if (!std::getenv("FAMSEQ_KERNEL_CACHE")) dirs.push_back(lib_dir() + "/kernels");  // (an explicit cache: that directory only)
+  try {
+    dirs.push_back(cache_dir());
+  } catch (const std::exception &) {
+  }
+  for (const std::string &d : dirs) {
+    std::ifstream f((d + "/" + name).c_str());
+    int v = -1;
+    if (f >> v) return v;
+  }
+  return -1;
+}
+
+void jit_write_pick(const std::string &key_source, int variant) {
+  const std::string path = cache_dir() + "/" + pick_name(key_source);
+  const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+  {
+    std::ofstream f(tmp.c_str());
+    f << variant << "\n";
+  }
+  ::rename(tmp.c_str(), path.c_str());
+}
+
 JitKernel jit_load(const std::string &source, const std::string &entry) {
   JitKernel k;
   k.path = jit_compile(source);

@@ -35,6 +35,10 @@ std::string jit_compile(const std::string &source, int *scratch_bytes = nullptr,
 // (`variant` 0 = most parallel).  Compiles variants in order and returns the source of the
 // first one that does not spill (more than 16 bytes per lane), or of the one that spills least.  *picked = its index.
 std::string jit_pick_variant(const std::function<std::string(int)> &generate, int n_variants, int *picked = nullptr, int first = 0);
+// The autotuner's note (famseq_set_option "tune"): which variant of the kernel whose variant-0 source is
+// `key_source` ran fastest on this machine — "<hash>.pick" next to the code objects.  -1: none.
+int jit_read_pick(const std::string &key_source);
+void jit_write_pick(const std::string &key_source, int variant);
 void jit_unload(JitKernel &k);
 
 }  // namespace famseq

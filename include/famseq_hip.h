@@ -114,6 +114,11 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *                   says otherwise; -1 (default) = the generated kernel, lanes per site chosen by batch size,
  *                   for batches of >= "lane_min_sites" (256) sites when it can be built, the team kernel
  *                   otherwise (tiny calls never wait for a compile)
+ *   "tune"          1 = time the candidates of this pedigree's generated kernels on this device (where a static rule
+ *                   picks a variant: the enumeration kernel's 7- or 6-member unrolled block, the sum-product kernel's
+ *                   fence variant) on synthetic rows, a few milliseconds each, and keep the winners' indices as notes
+ *                   in the kernel cache — every later context for the pedigree starts from them; compiles every
+ *                   candidate (seconds each), needs a device; famseq_plan_json "tune" reports what was measured
  *   "group_digits"  the generated kernel's lanes per site, 3^d: d = 0 one lane per site (large batches),
  *                   d = 1..4 lanes-per-site mode for batches too small to give every lane of the chip a
  *                   site (each lane of a group enumerates one combination of the d outermost looped

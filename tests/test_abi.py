@@ -142,3 +142,11 @@ def test_no_compiler_at_all_is_an_error_not_a_silent_path(tmp_path):
     rc, out, files = _compile_in_subprocess(tmp_path, {"FAMSEQ_HIPCC": "/nonexistent/hipcc", "FAMSEQ_NO_HIPRTC": "1"})
     assert rc != 0 and "compilation failed" in out, out
     assert not any(f.endswith(".hsaco") for f in files), files
+
+
+def test_tune_needs_a_device():
+    """famseq_set_option "tune" times kernels on the GPU: a plan-only context says so (and there is no CPU path to time)."""
+    ctx = fs.Context(fs.make_model(fs.synthetic_pedigree("trio")), device=-1)
+    with pytest.raises(fs.FamseqError, match="needs a device"):
+        ctx.set_option("tune", 1)
+    ctx.close()

@@ -213,3 +213,39 @@ def test_bench_launches_its_own_ranks(scaling):
     k = out["per_rank_kernel_ms"]
     assert len(k["all"]) == 2 and 0 < k["min"] <= k["max"]
     assert out["roofline"]["frac"] > 0
+
+
+def test_tune_times_the_variants_and_later_contexts_start_from_the_pick(tmp_path, monkeypatch):
+    """famseq_set_option "tune": the candidates of a pedigree's generated kernels are timed on this GPU and the winners'
+    indices kept as notes in the kernel cache; results stay what they were; a later context compiles the picked variant
+    only.  (A twelve-member, three-family pedigree: both block shapes exist, both fence variants apply.)"""
+    import json
+
+    monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
+    ped = fs.synthetic_pedigree("ped15:12")
+    model = fs.make_model(ped)
+    mo, fa = ped.relations()
+    lk, flags = fs.synth.gen_batch(mo, fa, 300, 4)
+    ctx = fs.Context(model, enum_impl=1)
+    before = ctx.bn_batch(lk, flags)
+    ctx.set_option("tune", 1)
+    plan = ctx.plan()
+    assert "enumeration (7- / 6-member block): v0" in plan["tune"] and "sum-product (fence variants): v0" in plan["tune"], plan["tune"]
+    assert plan["enum_lane_variant"] in (0, 2)
+    after = ctx.bn_batch(lk, flags)
+    np.testing.assert_allclose(after[0], before[0], rtol=1e-12, atol=0)
+    assert np.array_equal(after[1].view(np.uint64), before[1].view(np.uint64)) and np.array_equal(after[2], before[2])
+    ctx.set_option("engine", fs.ENGINE_ELIM)
+    by_elim = ctx.bn_batch(lk, flags)
+    np.testing.assert_allclose(by_elim[0], before[0], rtol=1e-9, atol=0)
+    picks = sorted(f.name for f in tmp_path.iterdir() if f.name.endswith(".pick"))
+    assert len(picks) == 2
+    lane_pick, elim_pick = plan["enum_lane_variant"], ctx.plan()["elim_variant"]
+    ctx.close()
+    # a later context: same picks, nothing timed
+    ctx = fs.Context(model, enum_impl=1)
+    ctx.set_option("engine", fs.ENGINE_ELIM)
+    p2 = ctx.plan()
+    ctx.close()
+    assert p2["enum_lane_variant"] == lane_pick and p2["elim_variant"] == elim_pick and p2["tune"] == ""
+
