@@ -622,8 +622,11 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << "  for (int i = tid; i < 432; i += BT) s_tc[i] = tc_g[i];\n"
     << "  const long chunks = (n_sites + BT - 1) / BT;\n"
     << (strided ? "  const long c_lo = blockIdx.x, c_hi = chunks;\n"
-                : "  const long per_wg = (chunks + gridDim.x - 1) / gridDim.x;\n"
-                  "  const long c_lo = (long)blockIdx.x * per_wg, c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;\n")
+                // contiguous ranges of q or q + 1 chunks: every workgroup of the grid has work (ceil(chunks / grid) each left
+                // a sixth of them idle at BASELINE's 1 M five-member sites: 15,625 chunks over 3,072 resident workgroups,
+                // 0.0705 -> 0.0662 ms)
+                : "  const long q_wg = chunks / gridDim.x, r_wg = chunks - q_wg * gridDim.x;\n"
+                  "  const long c_lo = (long)blockIdx.x * q_wg + (blockIdx.x < r_wg ? blockIdx.x : r_wg), c_hi = c_lo + q_wg + (blockIdx.x < r_wg ? 1 : 0);\n")
     << "  const double kNaN = __builtin_nan(\"\");\n"
     << "  double *row = s_io + tid * ROW;\n"
     // (regs_l = false) volatile forces a fresh LDS read per use.  The address space is spelled out:

@@ -761,8 +761,8 @@ std::string grouped_shell(const famseq_model &m, const std::string &comment, con
     << "  for (int i = tid; i < 432; i += BT) s_tc[i] = tc_g[i];\n"
     << "  const int sidx = tid / G, sub = tid - sidx * G;  // site within the chunk, lane within the group\n"
     << "  const long chunks = (n_sites + SPC - 1) / SPC;\n"
-    << "  const long per_wg = (chunks + gridDim.x - 1) / gridDim.x;\n"
-    << "  const long c_lo = (long)blockIdx.x * per_wg, c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;\n"
+    << "  const long q_wg = chunks / gridDim.x, r_wg = chunks - q_wg * gridDim.x;  // q or q + 1 chunks each: no idle workgroup\n"
+    << "  const long c_lo = (long)blockIdx.x * q_wg + (blockIdx.x < r_wg ? blockIdx.x : r_wg), c_hi = c_lo + q_wg + (blockIdx.x < r_wg ? 1 : 0);\n"
     << "  const double kNaN = __builtin_nan(\"\");\n"
     << "  double *row = s_io + tid * ROW;\n"
     << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
