@@ -629,6 +629,28 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
     if (value != 1) return fail(c, FAMSEQ_E_ARG, "tune takes 1");
     return tune(c);
   }
+  else if (k == "pick_lane" || k == "pick_elim") {  // a variant measured elsewhere (the table build() ships): the note tune() would leave
+    const bool lane = k == "pick_lane";
+    if (value < 0 || value >= (lane ? kEnumVariants : kElimVariants)) return fail(c, FAMSEQ_E_ARG, k + " takes a variant index");
+    if (!lane && !elim_supported(c->model, nullptr)) return fail(c, FAMSEQ_E_ARG, "pick_elim: the sum-product engine does not serve this pedigree");
+    try {
+      jit_write_pick(lane ? enumgen_source(c->model, 0, 0) : elim_source(c->model, 0), (int)value);
+    } catch (const std::exception &e) {
+      return fail(c, FAMSEQ_E_HIP, e.what());
+    }
+    if (lane) {  // whatever this context holds of that kernel is dropped; the next use starts from the note
+      jit_unload(c->lane), jit_unload(c->lane_call);
+      c->lane.path.clear(), c->lane_call.path.clear();
+      c->lane_variant = c->lane_call_variant = -1;
+      c->lane_reads_rows = -1;
+    } else {
+      jit_unload(c->elim);
+      c->elim.path.clear();
+      c->elim_variant = -1;
+      if (c->engine == FAMSEQ_ENGINE_ELIM) return load_elim(c);
+    }
+    return 0;
+  }
   else if (k == "call_kernels") {  // build (and on a device ctx load) the fused call-path forms now rather than on first use
     if (value != 1) return fail(c, FAMSEQ_E_ARG, "call_kernels takes 1");
     if (!load_call_kernel(c, false)) return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable: " + c->lane_error);

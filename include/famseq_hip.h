@@ -119,6 +119,8 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *                   fence variant) on synthetic rows, a few milliseconds each, and keep the winners' indices as notes
  *                   in the kernel cache — every later context for the pedigree starts from them; compiles every
  *                   candidate (seconds each), needs a device; famseq_plan_json "tune" reports what was measured
+ *   "pick_lane", "pick_elim"  a variant index measured elsewhere, kept as the note "tune" would leave (how build() ships
+ *                   its table of measured picks); works on a plan-only context
  *   "group_digits"  the generated kernel's lanes per site, 3^d: d = 0 one lane per site (large batches),
  *                   d = 1..4 lanes-per-site mode for batches too small to give every lane of the chip a
  *                   site (each lane of a group enumerates one combination of the d outermost looped

@@ -79,8 +79,45 @@ def test_variant_is_the_first_that_does_not_spill(tmp_path, monkeypatch):
         obj = p["elim_code_object"]
         assert obj.startswith(str(tmp_path))
         assert int(open(obj[:-6] + ".res").read()) == 0  # the variant in use has no scratch
-    assert picked == {"ped5": 0, "ped10": 1}
+    assert picked == {"ped5": 0, "ped10": 0}  # nothing spills, nothing has been measured here: the fence-free variant
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".res")]) == 2  # nothing else was compiled
+
+
+def test_a_measured_pick_is_where_the_picker_starts(tmp_path, monkeypatch):
+    """famseq_set_option "pick_elim" / "pick_lane" leave the note "tune" would (how build() ships its table of measured
+    picks, famseq_amd/tuned_picks.json): every later context for the pedigree compiles that variant, and only it."""
+    monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))
+    model = fs.make_model(fs.synthetic_pedigree("ped15"))
+    ctx = fs.Context(model, device=-1)
+    ctx.set_option("pick_elim", 1)
+    ctx.set_option("pick_lane", 2)
+    with pytest.raises(fs.FamseqError):
+        ctx.set_option("pick_elim", 7)
+    ctx.close()
+    ctx = fs.Context(model, device=-1)
+    ctx.set_option("enum_impl", 1)
+    ctx.set_option("engine", fs.ENGINE_ELIM)
+    p = ctx.plan()
+    ctx.close()
+    assert p["elim_variant"] == 1 and p["enum_lane_variant"] == 2
+    assert "= 729 configurations per step" in p["enum_lane_shape"]  # the 6-member block
+    assert sorted(f[-5:] for f in os.listdir(tmp_path)).count(".pick") == 2
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2
+
+
+def test_the_shipped_pick_table_matches_the_pedigrees_build_prebuilds():
+    import json
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+
+    table = json.load(open(ge.PICKS))
+    peds, _ = ge.build_pedigrees()
+    keys = {ge.pedigree_key(p) for p in peds}
+    assert keys == set(table), (len(keys), len(table))
+    assert all(v["lane"] in (0, 2) and v["elim"] in (-1, 0, 1) for v in table.values())
 
 
 def test_a_spilling_variant_is_passed_over(tmp_path, monkeypatch):
