@@ -497,10 +497,10 @@ int tune(famseq_ctx *c) {
   const famseq_model &mdl = c->model;
   const int N = mdl.n_members;
   // about 10 ms of enumeration per launch, 64 K - 2 M sites; the sum-product kernel, whose time does not grow with
-  // 3^N, always gets the 2 M (at 64 K sites its launch is most of what a timer sees)
+  // 3^N, always gets 8 M (at 64 K sites its launch is most of what a timer sees)
   const double want = 0.01 * 2.4e13 / std::pow(3.0, N);
   const int64_t n_enum = std::max<int64_t>(1 << 16, std::min<int64_t>(int64_t(1) << 21, (int64_t)want)) / 64 * 64;
-  const int64_t n_elim = int64_t(1) << 21, n_max = std::max(n_enum, n_elim);
+  const int64_t n_elim = int64_t(1) << 23, n_max = std::max(n_enum, n_elim);  // 8 M: it has to stream from HBM (2 M sites half fit the Infinity Cache)
   int64_t n = n_enum;  // sites of the launches being timed
   const size_t w = size_t(n_max) * 3 * N;
   double *d_lk = nullptr, *d_post = nullptr, *d_single = nullptr;
@@ -515,14 +515,19 @@ int tune(famseq_ctx *c) {
     return fail(c, FAMSEQ_E_HIP, "tune: device buffers");
   }
   {
-    std::vector<double> h(w);
+    // PL-shaped rows — one genotype at 1, the others 10^-(k/10) — for the first 64 K sites, doubled on the device from there
+    const size_t w0 = std::min(w, size_t(1 << 16) * 3 * N);
+    std::vector<double> h(w0);
     uint64_t z = 0x9E3779B97F4A7C15ull;
-    for (size_t i = 0; i < w; i += 3) {  // PL-shaped rows: one genotype at 1, the others 10^-(k/10)
+    for (size_t i = 0; i < w0; i += 3) {
       z = z * 6364136223846793005ull + 1442695040888963407ull;
       const unsigned a = unsigned(z >> 33) % 3, p1 = 3 + unsigned(z >> 40) % 88, p2 = p1 + unsigned(z >> 50) % 160;
       h[i + a] = 1.0, h[i + (a + 1) % 3] = std::pow(10.0, -0.1 * p1), h[i + (a + 2) % 3] = std::pow(10.0, -0.1 * p2);
     }
-    if (hipMemcpy(d_lk, h.data(), w * 8, hipMemcpyHostToDevice) != hipSuccess) {
+    bool up = hipMemcpy(d_lk, h.data(), w0 * 8, hipMemcpyHostToDevice) == hipSuccess;
+    for (size_t have = w0; up && have < w; have *= 2)
+      up = hipMemcpy(d_lk + have, d_lk, std::min(have, w - have) * 8, hipMemcpyDeviceToDevice) == hipSuccess;
+    if (!up) {
       release();
       return fail(c, FAMSEQ_E_HIP, "tune: upload");
     }

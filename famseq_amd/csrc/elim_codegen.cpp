@@ -377,12 +377,14 @@ int elim_conditioned_members(const famseq_model &m) {
 // sites 0.662 -> 0.617 ms, quads 0.507 -> 0.481; six members 0.459 -> 0.403 ms per 4 M sites, seven 0.570 -> 0.512,
 // eight 0.718 -> 0.607 (the fence-free variant at ONE wave per SIMD with its overflow in AGPRs), ten 0.664 -> 0.640 and
 // fifteen 1.118 -> 1.047 (the fence-per-message variant, which fits two waves): profiles/r02c/exp_elim_waves*.txt.
-// Which variant runs best is a property of the pedigree, not of its size: on 90 randomly grown pedigrees of 8-14 members
-// (PL-shaped rows, profiles/r02c/tune_survey.txt) the fence-free variant wins two times in three, and starting from it
-// loses 2.6 % on average to the better of the two where "the fenced one from nine members on" (fitted to the two
-// benchmark pedigrees, which both prefer the fenced one) loses 6.2 %.  So the picker starts from the fence-free
-// variant, and a pedigree that has been measured — famseq_set_option "tune", or the table of measured picks that
-// build() ships for the pedigrees it pre-builds — starts from its note.
+// Which variant runs best is a property of the pedigree more than of its size: on 90 randomly grown pedigrees of 8-14
+// members (PL-shaped rows; 2 M sites and, streaming from HBM, 8 M: profiles/r02c/tune_survey_*_sites.txt) the fence-free
+// variant wins two times in three, and starting from it loses 3.1 % on average to the better of the two where "the
+// fenced one from nine members on" (fitted to the two benchmark pedigrees, which both prefer the fenced one) loses
+// 5.6 %.  The one size that goes the other way in both surveys is eleven members (15 of 17 pedigrees, by 10 % on
+// average): with that exception 1.3 %.  So the picker starts from the fence-free variant, at eleven members from the
+// fenced one, and a pedigree that has been measured — famseq_set_option "tune", or the table of measured picks that
+// build() ships for the pedigrees it pre-builds (the benchmark pedigrees among them) — starts from its note.
 // The fused call-path form is another kernel — paced by the sixty logarithms per site between its barriers, not by
 // memory — and keeps 256-lane workgroups at two waves per SIMD: 0.317 ms per 1 M ten-member sites against 0.487 in
 // one-wave workgroups (tools/call_ab.sh).
@@ -392,7 +394,7 @@ int elim_block_threads(const famseq_model &m, bool call_mode) {
   return 64;
 }
 
-int elim_first_variant(const famseq_model &, bool) { return 0; }
+int elim_first_variant(const famseq_model &m, bool call_mode) { return !call_mode && m.n_members == 11 ? 1 : 0; }
 
 // Text every generated kernel carries for the fused call path (SURVEY.md 8(f) rows N2 + N4): packed
 // integer PLs staged straight into the LDS rows (the reference's lk = pow(10, -|PL| / 10), file.cpp:588-590,
