@@ -498,8 +498,14 @@ int tune(famseq_ctx *c) {
   const int N = mdl.n_members;
   // about 10 ms of enumeration per launch, 64 K - 2 M sites; the sum-product kernel, whose time does not grow with
   // 3^N, always gets 8 M (at 64 K sites its launch is most of what a timer sees)
-  const double want = 0.01 * 2.4e13 / std::pow(3.0, N);
-  const int64_t n_enum = std::max<int64_t>(1 << 16, std::min<int64_t>(int64_t(1) << 21, (int64_t)want)) / 64 * 64;
+  // ... in whole ROUNDS of the chip: a candidate at one wave per SIMD takes 64 K sites at a time, one at two waves 128 K;
+  // a batch of 2.3 rounds times the tail, not the kernel (a thirteen-member pedigree's two blocks came out 25 % apart that
+  // way).  Up to eight rounds while a launch stays under a quarter of a second.
+  const double configs = std::pow(3.0, N), t_round = 65536.0 * configs / 2.4e13;
+  int64_t rounds = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(0.25 / t_round)));
+  if (rounds > 1) rounds &= ~int64_t(1);
+  const int64_t by_time = (int64_t)(0.01 * 2.4e13 / configs) / 131072 * 131072;
+  const int64_t n_enum = std::min<int64_t>(int64_t(1) << 21, std::max<int64_t>(by_time, 65536 * rounds));
   const int64_t n_elim = int64_t(1) << 23, n_max = std::max(n_enum, n_elim);  // 8 M: it has to stream from HBM (2 M sites half fit the Infinity Cache)
   int64_t n = n_enum;  // sites of the launches being timed
   const size_t w = size_t(n_max) * 3 * N;
