@@ -577,7 +577,8 @@ int tune(famseq_ctx *c) {
       char buf[64];
       std::snprintf(buf, sizeof buf, " v%d %.4f ms", v, ms);
       report += buf;
-      if (ms > 0 && (win < 0 || ms < win_ms * 0.99)) win = v, win_ms = ms;  // a later candidate has to win by 1 %
+      if (ms > 0 && (win < 0 || ms < win_ms * 0.97)) win = v, win_ms = ms;  // a later candidate has to win by 3 % (two runs of one
+                                                                            // table disagreed on 17 of 78 pedigrees at 1 %: all within 2 %)
     }
     if (win >= 0) {
       jit_write_pick(gen(0), win);
