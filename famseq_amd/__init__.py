@@ -52,9 +52,30 @@ class CModel(C.Structure):
     ]
 
 
+class CPedigree(C.Structure):
+    """famseq_pedigree (include/famseq_hip.h): the size-independent model; the per-member arrays are numpy arrays
+    kept alive in ``_keep``."""
+    _fields_ = [
+        ("n_members", C.c_int32),
+        ("mother", C.POINTER(C.c_int32)),
+        ("father", C.POINTER(C.c_int32)),
+        ("gender", C.POINTER(C.c_int32)),
+        ("sequenced", C.POINTER(C.c_uint8)),
+        ("pcp2", C.c_double * 27),
+        ("pcp2Xf", C.c_double * 27),
+        ("pcp2Xm", C.c_double * 27),
+        ("genoProbN", C.c_double * 3),
+        ("genoProbK", C.c_double * 3),
+        ("genoProbXN", C.c_double * 3),
+        ("genoProbXK", C.c_double * 3),
+        ("lc", C.c_double),
+    ]
+
+
 # every symbol include/famseq_hip.h declares
 ABI_SYMBOLS = [
-    "famseq_transmission_tables", "famseq_model_init", "famseq_device_count", "famseq_create",
+    "famseq_transmission_tables", "famseq_model_init", "famseq_pedigree_init", "famseq_device_count", "famseq_create",
+    "famseq_create_pedigree",
     "famseq_destroy", "famseq_last_error", "famseq_set_option", "famseq_plan_json",
     "famseq_bn_batch", "famseq_bn_batch_sharded", "famseq_bn_batch_device", "famseq_bn_batch_device_sharded",
     "famseq_bn_call_batch", "famseq_alloc_pinned", "famseq_free_pinned", "famseq_stream_probe",
@@ -88,6 +109,10 @@ def lib():
     L.famseq_transmission_tables.restype = None
     L.famseq_model_init.argtypes = [mp, C.c_int32, ip, ip, ip, ip, bp, C.c_double, C.c_double]
     L.famseq_model_init.restype = C.c_int
+    L.famseq_pedigree_init.argtypes = [C.POINTER(CPedigree), C.c_int32, ip, ip, ip, ip, bp, C.c_double, C.c_double, ip, ip]
+    L.famseq_pedigree_init.restype = C.c_int
+    L.famseq_create_pedigree.argtypes = [C.POINTER(CPedigree), C.c_int, C.c_char_p, C.c_size_t]
+    L.famseq_create_pedigree.restype = C.c_void_p
     L.famseq_device_count.restype = C.c_int
     L.famseq_create.argtypes = [mp, C.c_int, C.c_char_p, C.c_size_t]
     L.famseq_create.restype = C.c_void_p
@@ -139,14 +164,23 @@ def device_count():
 
 
 def make_model(ped: Pedigree, mrate=1e-7, lc=1.0, genoProbN=None, genoProbK=None, genoProbXN=None,
-               genoProbXK=None, sequenced=None) -> CModel:
-    """family(mem, mRate) + set_genoProb* + set_lc + init()  (file.cpp:1888-1927)."""
-    m = CModel()
+               genoProbXK=None, sequenced=None, size_independent=False):
+    """family(mem, mRate) + set_genoProb* + set_lc + init()  (file.cpp:1888-1927).  Up to 20 members: the fixed
+    famseq_model; beyond (or size_independent=True): famseq_pedigree, which only the sum-product engine serves."""
     i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
     ids, mids, fids, gen = i32(ped.ids), i32(ped.mids), i32(ped.fids), i32(ped.genders)
     seq = np.ascontiguousarray(ped.sequenced if sequenced is None else sequenced, dtype=np.uint8)
-    rc = lib().famseq_model_init(C.byref(m), ped.n, _p(ids, C.c_int32), _p(mids, C.c_int32), _p(fids, C.c_int32),
-                                 _p(gen, C.c_int32), _p(seq, C.c_uint8), float(mrate), float(lc))
+    if ped.n > MAXN or size_independent:
+        m = CPedigree()
+        mo, fa = np.zeros(ped.n, np.int32), np.zeros(ped.n, np.int32)
+        m._keep = (gen, seq, mo, fa)  # the struct points into these
+        rc = lib().famseq_pedigree_init(C.byref(m), ped.n, _p(ids, C.c_int32), _p(mids, C.c_int32), _p(fids, C.c_int32),
+                                        _p(gen, C.c_int32), _p(seq, C.c_uint8), float(mrate), float(lc), _p(mo, C.c_int32),
+                                        _p(fa, C.c_int32))
+    else:
+        m = CModel()
+        rc = lib().famseq_model_init(C.byref(m), ped.n, _p(ids, C.c_int32), _p(mids, C.c_int32), _p(fids, C.c_int32),
+                                     _p(gen, C.c_int32), _p(seq, C.c_uint8), float(mrate), float(lc))
     if rc != 0:
         msg = {-10: "This is not a fulfill family. Please check the ped file.",
                -11: "a mother is not female or a father is not male"}.get(rc, "bad pedigree arguments")
@@ -162,11 +196,12 @@ def make_model(ped: Pedigree, mrate=1e-7, lc=1.0, genoProbN=None, genoProbK=None
 class Context:
     """famseq_ctx: one model bound to one GPU (device=-1: plan only, no compute)."""
 
-    def __init__(self, model: CModel, device=0, **options):
+    def __init__(self, model, device=0, **options):
         self.n = model.n_members
         self._model = model
         err = C.create_string_buffer(512)
-        self._h = lib().famseq_create(C.byref(model), int(device), err, len(err))
+        create = lib().famseq_create_pedigree if isinstance(model, CPedigree) else lib().famseq_create
+        self._h = create(C.byref(model), int(device), err, len(err))
         if not self._h:
             raise FamseqError("famseq_create: " + err.value.decode())
         for k, v in options.items():

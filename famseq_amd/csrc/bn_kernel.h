@@ -24,7 +24,7 @@ struct KParams {
 KParams make_kparams(const Plan &p, double lc);
 
 // 4 flag combos x 4 member kinds x 27 doubles: the factor-table block `Tc` (see bn_kernel.hip)
-void build_factor_tables(const famseq_model &m, double *tc /* 432 */);
+void build_factor_tables(const Model &m, double *tc /* 432 */);
 
 // Resident workgroups per CU for this plan (occupancy query), or <0 on error.
 int bn_enum_blocks_per_cu(const Plan &p, hipError_t *err);

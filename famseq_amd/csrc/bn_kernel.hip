@@ -409,7 +409,7 @@ KParams make_kparams(const Plan &p, double lc) {
   return k;
 }
 
-void build_factor_tables(const famseq_model &m, double *tc) {
+void build_factor_tables(const Model &m, double *tc) {
   for (int i = 0; i < 4 * 4 * 27; ++i) tc[i] = 0;
   for (int fl = 0; fl < 4; ++fl) {
     const bool known = fl & FAMSEQ_FLAG_KNOWN, x = fl & FAMSEQ_FLAG_CHRX;

@@ -41,7 +41,8 @@ struct CallIO {  // = struct fs_call_args of the generated source (elim_codegen.
 };
 
 struct famseq_ctx {
-  famseq_model model{};
+  Model model;
+  bool big = false;  // more than FAMSEQ_MAX_MEMBERS members: no enumeration plan, sum-product engine only
   PlanOptions opt{};
   Plan plan{};
   KParams kp{};
@@ -62,8 +63,13 @@ struct famseq_ctx {
   int enum_impl = -1;
   JitKernel lane{};  // one lane per site (large batches)
   int lane_blocks_per_cu = 0;
-  bool lane_failed = false;
+  bool lane_failed = false;  // the plain one-lane-per-site kernel could not be built (no compiler at run time, ...)
   std::string lane_error;
+  // every other generated kernel keeps its own verdict: a call-path form that does not build must not take the plain
+  // kernels down with it, nor the other way round
+  bool grp_failed[kEnumMaxGroupDigits + 1] = {};
+  bool call_failed[2] = {false, false};  // [0] lane call-path form, [1] sum-product call-path form
+  std::string call_error[2];
   // lanes-per-site mode of the same generator for batches too small to give every lane of the chip a
   // site: grp[d] lets 3^d lanes share a site (d = 1..4 of the outermost looped members' digits on
   // lanes).  Compiled on first use of each d.  group_digits: -1 auto (by batch size), 0..4 forced.
@@ -118,9 +124,11 @@ int fail(famseq_ctx *c, int code, const std::string &msg) {
       return fail((c), FAMSEQ_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
   } while (0)
 
-void validate_model(const famseq_model &m) {
+void validate_model(const Model &m) {
   const int n = m.n_members;
-  if (n < 1 || n > FAMSEQ_MAX_MEMBERS) throw std::runtime_error("n_members must be 1..20");
+  if (n < 1) throw std::runtime_error("n_members must be >= 1 (and the member arrays given)");
+  if ((int)m.mother.size() != n || (int)m.father.size() != n || (int)m.gender.size() != n || (int)m.sequenced.size() != n)
+    throw std::runtime_error("member arrays do not match n_members");
   for (int i = 0; i < n; ++i) {
     const int mo = m.mother[i], fa = m.father[i];
     if ((mo < 0) != (fa < 0)) throw std::runtime_error("member with exactly one known parent");
@@ -167,25 +175,29 @@ void free_slots(famseq_ctx *c) {
 // (Re)build the plan and, on a device ctx, upload its image and the factor tables.
 int refresh_plan(famseq_ctx *c) {
   if (!c->plan_dirty) return 0;
-  try {
-    c->plan = build_plan(c->model, c->opt);
-  } catch (const std::exception &e) {
-    return fail(c, FAMSEQ_E_ARG, std::string("plan: ") + e.what());
+  if (!c->big) {
+    try {
+      c->plan = build_plan(c->model, c->opt);
+    } catch (const std::exception &e) {
+      return fail(c, FAMSEQ_E_ARG, std::string("plan: ") + e.what());
+    }
+    c->kp = make_kparams(c->plan, c->model.lc);
   }
-  c->kp = make_kparams(c->plan, c->model.lc);
   if (c->device >= 0) {
     HIP_TRY(c, hipSetDevice(c->device));
+    double tc[4 * 4 * 27];
+    build_factor_tables(c->model, tc);
+    if (!c->d_tc) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_tc), sizeof tc));
+    HIP_TRY(c, hipMemcpy(c->d_tc, tc, sizeof tc, hipMemcpyHostToDevice));
+  }
+  if (c->device >= 0 && !c->big) {
     std::vector<uint32_t> img = c->plan.device_image();
-    for (int i = 0; i < c->plan.N; ++i)
+    for (int i = 0; i < c->model.n_members; ++i)
       img[c->kp.off_minfo + i] |= uint32_t(c->model.sequenced[i] ? 1 : 0) << 2;
     if (c->d_img) (void)hipFree(c->d_img);
     c->d_img = nullptr;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_img), img.size() * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpy(c->d_img, img.data(), img.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    double tc[4 * 4 * 27];
-    build_factor_tables(c->model, tc);
-    if (!c->d_tc) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_tc), sizeof tc));
-    HIP_TRY(c, hipMemcpy(c->d_tc, tc, sizeof tc, hipMemcpyHostToDevice));
     hipError_t e = hipSuccess;
     c->blocks_per_cu = bn_enum_blocks_per_cu(c->plan, &e);
     if (c->blocks_per_cu < 1)
@@ -207,11 +219,17 @@ int load_elim(famseq_ctx *c) {
   std::string why;
   if (!elim_supported(c->model, &why)) return fail(c, FAMSEQ_E_ARG, "elimination engine: " + why);
   try {
-    const famseq_model &mdl = c->model;
-    int first = elim_first_variant(mdl);
-    const int pick = jit_read_pick(elim_source(mdl, 0));  // the autotuner's note, where this pedigree has been tuned here
-    if (pick >= 0 && pick < kElimVariants) first = pick;
-    const std::string src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v); }, kElimVariants, &c->elim_variant, first);
+    const Model &mdl = c->model;
+    // a measured pick (the autotuner's note, or the table build() ships) is loaded as it is: the spill contest below is
+    // the static rule for pedigrees nobody has measured, and must not move off a measurement
+    const int pick = jit_read_pick(elim_source(mdl, 0));
+    std::string src;
+    if (pick >= 0 && pick < kElimVariants) {
+      src = elim_source(mdl, pick);
+      c->elim_variant = pick;
+    } else {
+      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v); }, kElimVariants, &c->elim_variant, elim_first_variant(mdl));
+    }
     if (c->device < 0) {  // plan-only ctx: generate and compile into the cache (this is how build() pre-builds)
       c->elim.path = jit_compile(src);
       return 0;
@@ -233,16 +251,19 @@ int load_elim(famseq_ctx *c) {
 bool load_lane(famseq_ctx *c, int d = 0) {
   JitKernel &k = d == 0 ? c->lane : c->grp[d];
   if (k.fn) return true;
-  if (c->lane_failed) return false;
+  if (d == 0 ? c->lane_failed : c->grp_failed[d]) return false;
   if (c->device < 0 && !k.path.empty()) return true;
   try {
-    const famseq_model &mdl = c->model;
-    int variant = -1, first = 0;
-    if (d == 0) {
-      const int pick = jit_read_pick(enumgen_source(mdl, 0, 0));  // the autotuner's note (7- or 6-member block)
-      if (pick >= 0 && pick < kEnumVariants) first = pick;
+    const Model &mdl = c->model;
+    int variant = -1;
+    std::string src;
+    const int pick = d == 0 ? jit_read_pick(enumgen_source(mdl, 0, 0)) : -1;  // the autotuner's note (7- or 6-member block)
+    if (pick >= 0 && pick < kEnumVariants) {  // measured: exactly that variant (see load_elim)
+      src = enumgen_source(mdl, pick, d);
+      variant = pick;
+    } else {
+      src = jit_pick_variant([&mdl, d](int v) { return enumgen_source(mdl, v, d); }, kEnumVariants, &variant, 0);
     }
-    const std::string src = jit_pick_variant([&mdl, d](int v) { return enumgen_source(mdl, v, d); }, kEnumVariants, &variant, first);
     if (d == 0) c->lane_variant = variant;
     if (c->device < 0) {
       k.path = jit_compile(src);
@@ -256,12 +277,15 @@ bool load_lane(famseq_ctx *c, int d = 0) {
     (d == 0 ? c->lane_blocks_per_cu : c->grp_blocks_per_cu[d]) = nb > 0 ? nb : 1;
     return true;
   } catch (const std::exception &e) {
-    c->lane_failed = true;
-    c->lane_error = e.what();
-    // said once per ctx, where a user of the CLI or of the library sees it (also in famseq_plan_json)
+    if (d == 0) c->lane_failed = true;
+    else c->grp_failed[d] = true;
+    if (d == 0 || c->lane_error.empty()) c->lane_error = e.what();
+    // said once per ctx and kernel, where a user of the CLI or of the library sees it (also in famseq_plan_json)
     if (!std::getenv("FAMSEQ_QUIET"))
-      std::fprintf(stderr, "famseq: the per-pedigree enumeration kernel is unavailable (%s); large batches fall back to the "
-                           "compiled-in team-per-site kernel (about 4x slower)\n", c->lane_error.substr(0, 300).c_str());
+      std::fprintf(stderr, "famseq: the per-pedigree enumeration kernel%s is unavailable (%s); %s\n", d ? " (lanes-per-site form)" : "",
+                   std::string(e.what()).substr(0, 300).c_str(),
+                   d ? "such batches take the one-lane-per-site or the compiled-in kernel"
+                     : "large batches fall back to the compiled-in team-per-site kernel (about 4x slower)");
     return false;
   }
 }
@@ -315,7 +339,8 @@ hipError_t launch_engine(famseq_ctx *c, int64_t n_sites, const double *d_lk, con
   if (c->engine == FAMSEQ_ENGINE_ELIM) return launch_elim(c, n_sites, d_lk, d_flags, d_post, d_single, d_status, stream);
   const bool want_lane = c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites);
   if (want_lane) {
-    const int d = pick_group_digits(c, n_sites);
+    int d = pick_group_digits(c, n_sites);
+    if (d > 0 && !load_lane(c, d)) d = 0;  // that group size does not build: one lane per site before the compiled-in kernel
     if (load_lane(c, d)) {
       c->last_group_digits = d;
       if (d > 0)
@@ -337,16 +362,17 @@ hipError_t launch_engine(famseq_ctx *c, int64_t n_sites, const double *d_lk, con
 bool load_call_kernel(famseq_ctx *c, bool elim) {
   JitKernel &k = elim ? c->elim_call : c->lane_call;
   if (k.fn) return true;
-  if (c->lane_failed) return false;
+  if (c->call_failed[elim]) return false;
+  if (c->device < 0 && !k.path.empty()) return true;
   try {
-    const famseq_model &mdl = c->model;
+    const Model &mdl = c->model;
     std::string src;
     if (elim) {
       src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants, nullptr, elim_first_variant(mdl, true));
     } else {
       // the same block size as the plain lane kernel runs with (variants 0-1 / 2-3: kEnumVariants), so that a batch
       // gives the same bits whether it goes through the fused kernel or through the separate stages
-      if (!load_lane(c, 0)) return false;
+      if (!load_lane(c, 0)) throw std::runtime_error("the plain lane kernel is unavailable: " + c->lane_error);
       const int base = c->lane_variant >= 0 ? (c->lane_variant & ~1) : 0;
       int pick = 0;
       src = jit_pick_variant([&mdl, base](int v) { return enumgen_source(mdl, base + v, 0, true); }, 2, &pick);
@@ -365,8 +391,12 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
     (elim ? c->elim_call_blocks_per_cu : c->lane_call_blocks_per_cu) = nb > 0 ? nb : 1;
     return true;
   } catch (const std::exception &e) {
-    c->lane_failed = true;
-    c->lane_error = e.what();
+    c->call_failed[elim] = true;
+    c->call_error[elim] = e.what();
+    if (!std::getenv("FAMSEQ_QUIET"))
+      std::fprintf(stderr, "famseq: the fused call-path form of the %s kernel is unavailable (%s); famseq_bn_call_batch runs the "
+                           "separate unpack / posterior / Phred stages instead (same results)\n",
+                   elim ? "sum-product" : "enumeration", c->call_error[elim].substr(0, 300).c_str());
     return false;
   }
 }
@@ -378,6 +408,7 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
 bool launch_engine_fused(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, uint8_t *d_status,
                          bool packed_in, const CallIO *d_io, hipStream_t stream, hipError_t *err) {
   const bool elim = c->engine == FAMSEQ_ENGINE_ELIM;
+  if (c->big) return false;  // no call-path form of the wide-pedigree kernel: separate stages
   if (!elim) {
     const bool want_lane = c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites);
     if (!want_lane || pick_group_digits(c, n_sites) != 0) return false;
@@ -399,13 +430,35 @@ extern "C" int famseq_device_count(void) {
   return n;
 }
 
+namespace {
+famseq_ctx *create_ctx(const Model &model, int device_id, char *err, size_t errlen);
+}
+
 extern "C" famseq_ctx *famseq_create(const famseq_model *model, int device_id, char *err, size_t errlen) {
   if (!model) {
     set_err(err, errlen, "model is NULL");
     return nullptr;
   }
+  if (model->n_members < 1 || model->n_members > FAMSEQ_MAX_MEMBERS) {
+    set_err(err, errlen, "n_members must be 1..20 (famseq_model; famseq_pedigree has no limit)");
+    return nullptr;
+  }
+  return create_ctx(Model(*model), device_id, err, errlen);
+}
+
+extern "C" famseq_ctx *famseq_create_pedigree(const famseq_pedigree *pedigree, int device_id, char *err, size_t errlen) {
+  if (!pedigree) {
+    set_err(err, errlen, "pedigree is NULL");
+    return nullptr;
+  }
+  return create_ctx(Model(*pedigree), device_id, err, errlen);
+}
+
+namespace {
+famseq_ctx *create_ctx(const Model &model, int device_id, char *err, size_t errlen) {
   famseq_ctx *c = new famseq_ctx;
-  c->model = *model;
+  c->model = model;
+  c->big = model.n_members > FAMSEQ_MAX_MEMBERS;
   try {
     validate_model(c->model);
   } catch (const std::exception &e) {
@@ -454,8 +507,17 @@ extern "C" famseq_ctx *famseq_create(const famseq_model *model, int device_id, c
     famseq_destroy(c);
     return nullptr;
   }
+  if (c->big) {  // beyond the enumeration's reach: the sum-product engine or nothing
+    if (load_elim(c) != 0) {
+      set_err(err, errlen, "a pedigree of " + std::to_string(model.n_members) + " members is served by the sum-product engine only: " + c->err);
+      famseq_destroy(c);
+      return nullptr;
+    }
+    c->engine = FAMSEQ_ENGINE_ELIM;
+  }
   return c;
 }
+}  // namespace
 
 extern "C" void famseq_destroy(famseq_ctx *c) {
   if (!c) return;
@@ -494,7 +556,7 @@ namespace {
 int tune(famseq_ctx *c) {
   if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "tuning times kernels: it needs a device");
   HIP_TRY(c, hipSetDevice(c->device));
-  const famseq_model &mdl = c->model;
+  const Model &mdl = c->model;
   const int N = mdl.n_members;
   // about 10 ms of enumeration per launch, 64 K - 2 M sites; the sum-product kernel, whose time does not grow with
   // 3^N, always gets 8 M (at 64 K sites its launch is most of what a timer sees)
@@ -612,11 +674,14 @@ int tune(famseq_ctx *c) {
   c->lane_variant = c->lane_call_variant = c->elim_variant = -1;
   c->lane_reads_rows = -1;
   if (had_lane && !load_lane(c)) return fail(c, FAMSEQ_E_HIP, "lane kernel unavailable after tuning: " + c->lane_error);
-  if (had_lc && !load_call_kernel(c, false)) return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable after tuning: " + c->lane_error);
+  if (had_lc && !load_call_kernel(c, false)) return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable after tuning: " + c->call_error[0]);
   if (had_elim || c->engine == FAMSEQ_ENGINE_ELIM) {
     const int rc = load_elim(c);
     if (rc != 0) return rc;
   }
+  if (c->lane_variant >= 0 || c->elim_variant >= 0)  // what this context runs from here on (the notes are honoured as written)
+    c->tune_report += "; loaded:" + (c->lane_variant >= 0 ? " enumeration v" + std::to_string(c->lane_variant) : std::string()) +
+                      (c->elim_variant >= 0 ? " sum-product v" + std::to_string(c->elim_variant) : std::string());
   return 0;
 }
 
@@ -625,6 +690,13 @@ int tune(famseq_ctx *c) {
 extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) {
   if (!c || !key) return FAMSEQ_E_ARG;
   const std::string k(key);
+  if (c->big) {  // no enumeration here: its knobs have nothing to act on
+    for (const char *e : {"fixed_digits", "low_members", "block_threads", "enum_impl", "group_digits", "pick_lane", "tune", "lane_min_sites"})
+      if (k == e) return fail(c, FAMSEQ_E_ARG, "option " + k + " belongs to the enumeration engine, which serves up to 20 members");
+    if (k == "engine" && value == FAMSEQ_ENGINE_ENUM)
+      return fail(c, FAMSEQ_E_ARG, "the 3^N enumeration serves up to 20 members; this pedigree has " + std::to_string(c->model.n_members));
+    if (k == "call_kernels") return 0;  // (the call path of such a pedigree runs as separate stages)
+  }
   PlanOptions saved = c->opt;
   if (k == "fixed_digits") c->opt.fixed_digits = (int)value;
   else if (k == "low_members") c->opt.low_members = (int)value;
@@ -665,9 +737,9 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
   }
   else if (k == "call_kernels") {  // build (and on a device ctx load) the fused call-path forms now rather than on first use
     if (value != 1) return fail(c, FAMSEQ_E_ARG, "call_kernels takes 1");
-    if (!load_call_kernel(c, false)) return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable: " + c->lane_error);
+    if (!load_call_kernel(c, false)) return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable: " + c->call_error[0]);
     if (elim_supported(c->model, nullptr) && !load_call_kernel(c, true))
-      return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable: " + c->lane_error);
+      return fail(c, FAMSEQ_E_HIP, "call-path kernel unavailable: " + c->call_error[1]);
     return 0;
   }
   else if (k == "group_digits") {
@@ -720,6 +792,13 @@ std::string json_str(const std::string &v) {  // paths may hold quotes or backsl
 
 extern "C" const char *famseq_plan_json(famseq_ctx *c) {
   if (!c) return "{}";
+  if (c->big) {
+    c->json = "{\"N\":" + std::to_string(c->model.n_members) + ",\"engine\":" + std::to_string(c->engine) + ",\"elim_supported\":1,\"elim_code_object\":\"" +
+              json_str(c->elim.path) + "\",\"elim_variant\":" + std::to_string(c->elim_variant) + ",\"elim_blocks_per_cu\":" +
+              std::to_string(c->elim_blocks_per_cu) + ",\"elim_conditioned_members\":" + std::to_string(elim_conditioned_members(c->model)) +
+              ",\"enum_supported\":0,\"device\":" + std::to_string(c->device) + ",\"cus\":" + std::to_string(c->n_cus) + "}";
+    return c->json.c_str();
+  }
   c->json = c->plan.json();
   c->json.pop_back();
   c->json += ",\"engine\":" + std::to_string(c->engine) + ",\"elim_supported\":" +
@@ -735,7 +814,8 @@ extern "C" const char *famseq_plan_json(famseq_ctx *c) {
              std::to_string(c->last_group_digits) + ",\"enum_group_code_objects\":[";
   for (int d = 1; d <= kEnumMaxGroupDigits; ++d) c->json += std::string(d > 1 ? "," : "") + "\"" + json_str(c->grp[d].path) + "\"";
   c->json += "],\"enum_lane_call_code_object\":\"" + json_str(c->lane_call.path) + "\",\"elim_call_code_object\":\"" +
-             json_str(c->elim_call.path) + "\",\"enum_lane_call_reads_rows\":" + std::to_string(c->lane_reads_rows) + ",\"tune\":\"" +
+             json_str(c->elim_call.path) + "\",\"enum_lane_call_error\":\"" + json_str(c->call_error[0].substr(0, 300)) + "\",\"elim_call_error\":\"" +
+             json_str(c->call_error[1].substr(0, 300)) + "\",\"enum_lane_call_reads_rows\":" + std::to_string(c->lane_reads_rows) + ",\"tune\":\"" +
              json_str(c->tune_report) + "\"}";
   return c->json.c_str();
 }
@@ -765,15 +845,15 @@ struct HostIO {
 
 // Upload the sequenced-member list (VCF column order) and its inverse when it changes.
 int set_sequenced(famseq_ctx *c, const int32_t *seq, int n_seq) {
-  if (n_seq < 0 || n_seq > c->plan.N || (n_seq > 0 && !seq)) return fail(c, FAMSEQ_E_ARG, "bad sequenced-member list");
-  std::vector<int32_t> v(seq, seq + n_seq), col(c->plan.N, -1);
+  if (n_seq < 0 || n_seq > c->model.n_members || (n_seq > 0 && !seq)) return fail(c, FAMSEQ_E_ARG, "bad sequenced-member list");
+  std::vector<int32_t> v(seq, seq + n_seq), col(c->model.n_members, -1);
   for (int k = 0; k < n_seq; ++k) {
-    if (v[k] < 0 || v[k] >= c->plan.N || col[v[k]] >= 0) return fail(c, FAMSEQ_E_ARG, "bad sequenced-member list");
+    if (v[k] < 0 || v[k] >= c->model.n_members || col[v[k]] >= 0) return fail(c, FAMSEQ_E_ARG, "bad sequenced-member list");
     col[v[k]] = k;
   }
   if (c->d_seq && v == c->seq_members) return 0;
-  if (!c->d_seq) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_seq), FAMSEQ_MAX_MEMBERS * sizeof(int32_t)));
-  if (!c->d_col) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_col), FAMSEQ_MAX_MEMBERS * sizeof(int32_t)));
+  if (!c->d_seq) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_seq), c->model.n_members * sizeof(int32_t)));
+  if (!c->d_col) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_col), c->model.n_members * sizeof(int32_t)));
   if (n_seq) HIP_TRY(c, hipMemcpy(c->d_seq, v.data(), n_seq * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_col, col.data(), col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   c->seq_members = v;
@@ -790,7 +870,7 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
   if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
   if (n_sites == 0) return 0;
   HIP_TRY(c, hipSetDevice(c->device));
-  const int N = c->plan.N;
+  const int N = c->model.n_members;
   const size_t row = size_t(3) * N * sizeof(double);
   const bool called = io.gpp || io.fpp || io.fgt;
   // default chunk: at most 64 MiB per array, at least four chunks per call so that the stages overlap,
@@ -860,7 +940,7 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
 }
 
 int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int64_t chunk) {
-  const int N = c->plan.N;
+  const int N = c->model.n_members;
   const size_t row = size_t(3) * N * sizeof(double);
   const bool called = io.gpp || io.fpp || io.fgt;
   hipStream_t s_in = c->stream[0], s_k = c->stream[1], s_out = c->stream[2];
@@ -929,9 +1009,9 @@ extern "C" int famseq_bn_batch_sharded(famseq_ctx *const *ctxs, int n_ctx, int64
                                        const uint8_t *flags, double *post, double *post_single, uint8_t *status) {
   if (!ctxs || n_ctx < 1) return FAMSEQ_E_ARG;
   for (int g = 0; g < n_ctx; ++g)
-    if (!ctxs[g] || ctxs[g]->plan.N != ctxs[0]->plan.N) return FAMSEQ_E_ARG;
+    if (!ctxs[g] || ctxs[g]->model.n_members != ctxs[0]->model.n_members) return FAMSEQ_E_ARG;
   if (n_sites < 0 || (n_sites > 0 && (!lk || !post))) return fail(ctxs[0], FAMSEQ_E_ARG, "bad batch arguments");
-  const int64_t w = int64_t(3) * ctxs[0]->plan.N;
+  const int64_t w = int64_t(3) * ctxs[0]->model.n_members;
   std::vector<int> rc(n_ctx, 0);
   std::vector<std::thread> pool;
   for (int g = 0; g < n_ctx; ++g)
@@ -951,7 +1031,7 @@ extern "C" int famseq_bn_batch_device_sharded(famseq_ctx *const *ctxs, int n_ctx
                                               double *const *d_post, double *const *d_single, uint8_t *const *d_status) {
   if (!ctxs || n_ctx < 1 || !n_sites || !d_lk || !d_post) return FAMSEQ_E_ARG;
   for (int g = 0; g < n_ctx; ++g) {
-    if (!ctxs[g] || ctxs[g]->plan.N != ctxs[0]->plan.N) return FAMSEQ_E_ARG;
+    if (!ctxs[g] || ctxs[g]->model.n_members != ctxs[0]->model.n_members) return FAMSEQ_E_ARG;
     if (ctxs[g]->device < 0) return fail(ctxs[g], FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
     if (n_sites[g] < 0 || (n_sites[g] > 0 && (!d_lk[g] || !d_post[g]))) return fail(ctxs[g], FAMSEQ_E_ARG, "bad batch arguments");
   }

@@ -95,7 +95,7 @@ bool forest_without(const Graph &g, const std::vector<int> &cut, std::vector<int
   return true;
 }
 
-bool build_graph(const famseq_model &m, Graph &g, std::string *why) {
+bool build_graph(const Model &m, Graph &g, std::string *why) {
   g.N = m.n_members;
   std::map<std::pair<int, int>, int> idx;
   g.nb.assign(g.N, {});
@@ -143,7 +143,7 @@ bool build_graph(const famseq_model &m, Graph &g, std::string *why) {
 
 class Emitter {
  public:
-  Emitter(const famseq_model &m, const Graph &g, int fences, bool scalar_t) : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t) {}
+  Emitter(const Model &m, const Graph &g, int fences, bool scalar_t) : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t) {}
 
   std::string body() {
     if (g_.cut.empty()) {
@@ -214,7 +214,7 @@ class Emitter {
   }
 
  private:
-  const famseq_model &m_;
+  const Model &m_;
   const Graph &g_;
   const int fences_;  // 0 none, 1 after every family->member message, 2 also after local factors and child sums
   const bool scalar_t_;  // transmission entries from tcx[] (uniform pointer: scalar loads) instead of the lane's LDS table
@@ -363,12 +363,12 @@ class Emitter {
 
 }  // namespace
 
-bool elim_supported(const famseq_model &m, std::string *why) {
+bool elim_supported(const Model &m, std::string *why) {
   Graph g;
   return build_graph(m, g, why);
 }
 
-int elim_conditioned_members(const famseq_model &m) {
+int elim_conditioned_members(const Model &m) {
   Graph g;
   return build_graph(m, g, nullptr) ? (int)g.cut.size() : -1;
 }
@@ -388,13 +388,13 @@ int elim_conditioned_members(const famseq_model &m) {
 // The fused call-path form is another kernel — paced by the sixty logarithms per site between its barriers, not by
 // memory — and keeps 256-lane workgroups at two waves per SIMD: 0.317 ms per 1 M ten-member sites against 0.487 in
 // one-wave workgroups (tools/call_ab.sh).
-int elim_block_threads(const famseq_model &m, bool call_mode) {
+int elim_block_threads(const Model &m, bool call_mode) {
   if (const char *e = std::getenv("FAMSEQ_ELIM_BT")) return std::atoi(e);  // tuning aid
   if (call_mode) return m.n_members <= 10 ? 256 : 128;
   return 64;
 }
 
-int elim_first_variant(const famseq_model &m, bool call_mode) { return !call_mode && m.n_members == 11 ? 1 : 0; }
+int elim_first_variant(const Model &m, bool call_mode) { return !call_mode && m.n_members == 11 ? 1 : 0; }
 
 // Text every generated kernel carries for the fused call path (SURVEY.md 8(f) rows N2 + N4): packed
 // integer PLs staged straight into the LDS rows (the reference's lk = pow(10, -|PL| / 10), file.cpp:588-590,
@@ -407,6 +407,11 @@ const char FS_PHRED_TEXT_[] =
 #include "phred_src.h"
     ;
 #undef FS_PHRED_DEF
+#define FS_TAB_ROW(a, b) #a ", " #b ",\n"
+const char FS_TAB_TEXT_[] =
+#include "phred_tab.h"
+    ;
+#undef FS_TAB_ROW
 const std::string kCallHelpers = std::string(R"(
 #ifndef FS_RCP
 #define FS_RCP(x) __builtin_amdgcn_rcp(x)
@@ -415,18 +420,20 @@ const std::string kCallHelpers = std::string(R"(
 #define FS_UMULHI(a, b) __umulhi(a, b)
 #define FS_IS_POS_FINITE(x) __builtin_amdgcn_class(x, 0x180)  /* +normal | +denormal */
 #define FS_KEEP_BRANCH() asm volatile("" ::: "memory")
+#define FS_HI32(x) __double2hiint(x)
 #endif
+typedef double fs_v2d __attribute__((ext_vector_type(2)));
 // Pointers that reach the kernel through the argument struct are generic to the compiler, and every access
 // through them would be a flat_* instruction (counted on both vmcnt and lgkmcnt, waited for with both at 0).
 // They are global memory: say so.
 #ifndef FS_GLOBAL
 #define FS_GLOBAL __attribute__((address_space(1)))
 #endif
-)") + FS_PHRED_TEXT_ + std::string(R"(
+)") + FS_PHRED_TEXT_ + "\n// fs_phred's table (phred_tab.h): staged into LDS (s_lt) at kernel start\n__device__ const double fs_logtab[258] = {\n" +
+                                 FS_TAB_TEXT_ + "};\n" + std::string(R"(
 // The call path's arguments sit in one small struct in device memory behind a pointer that is null on the
 // plain path: its fields are fetched (scalar loads) only inside the stages that use them.  As ten more
 // kernel arguments they stayed live in SGPRs for the whole kernel and pushed the arithmetic into scratch.
-typedef double fs_v2d __attribute__((ext_vector_type(2)));
 struct fs_call_args {
   const FS_GLOBAL unsigned short *pl;  // [n_sites][n_seq][3] packed PLs, or null: fp64 likelihood rows come in as usual
   const FS_GLOBAL double *lut;         // pow(10, -k / 10), k < 4096
@@ -457,7 +464,7 @@ struct fs_call_args {
     signed char pk_ = -1; double bs_ = -1; \
     if (bs_ < d0_) { bs_ = d0_; pk_ = 0; } if (bs_ < d1_) { bs_ = d1_; pk_ = 1; } if (bs_ < d2_) { bs_ = d2_; pk_ = 2; } \
     s_fgt[tid * NMEM + p_] = pk_; \
-    row[3 * p_] = fs_phred(d0_); row[3 * p_ + 1] = fs_phred(d1_); row[3 * p_ + 2] = fs_phred(d2_); } }
+    row[3 * p_] = fs_phred(d0_, s_lt); row[3 * p_ + 1] = fs_phred(d1_, s_lt); row[3 * p_ + 2] = fs_phred(d2_, s_lt); } }
 // rows -> [site][VCF column][genotype], coalesced; FGT likewise from the byte table
 #define CALL_ELEM(e_) { const int s_ = (int)FS_UMULHI((unsigned)(e_), mg_), r_ = (e_) - s_ * w_, k_ = (r_ * 171) >> 9; \
     __builtin_nontemporal_store(s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)], g_ + (e_)); }
@@ -481,7 +488,7 @@ const char kCallArgs[] = ", const struct fs_call_args *__restrict__ call_g";
 // Statements of the single posterior (family.cpp:1426-1445) and of the shortcut vote (:767-789), the
 // same as in bn_kernel.hip; they read l<p>_<g> and tcf[], set single_fail / full, and (store) write
 // the normalised rows to row[].  Shared by every generated shell.
-std::string single_posterior_statements(const famseq_model &m, bool flags_pass, bool store, bool fence_single) {
+std::string single_posterior_statements(const Model &m, bool flags_pass, bool store, bool fence_single) {
   std::ostringstream s;
   const int N = m.n_members;
   for (int p = 0; p < N; ++p) {
@@ -511,7 +518,7 @@ std::string single_posterior_statements(const famseq_model &m, bool flags_pass, 
 //   regs_l = false: l<p>_<g> read the LDS row each time (short live ranges, no spills in the
 //                   message-passing code); the body writes the marginals to q[0..W3) and runs
 //                   BEFORE the single posterior takes over the row.
-std::string kernel_shell(const famseq_model &m, const std::string &entry, const std::string &comment,
+std::string kernel_shell(const Model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
                          bool chrx_loop, int row_doubles, bool call_mode, bool lane_body) {
   // ROW: the lane's LDS row, W3 doubles padded to an odd count (conflict-free ds_read_b64); a
@@ -645,6 +652,8 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
     << (call_mode ? "  const bool packed_in = call_g->pl != nullptr;  // fed with packed PLs (else fp64 rows)\n"
                     "  __shared__ int s_col[NMEM], s_seq[NMEM];  // member -> VCF column or -1; VCF column -> member\n"
                     "  __shared__ signed char s_fgt[BT * NMEM];  // arg-max genotype of every member of every site of the chunk\n"
+                    "  __shared__ __attribute__((aligned(16))) double s_lt[258];  // fs_phred's table: one 16-byte LDS read per logarithm\n"
+                    "  for (int i = tid; i < 258; i += BT) s_lt[i] = fs_logtab[i];\n"
                     "  for (int i = tid; i < NMEM; i += BT) { s_col[i] = call_g->col[i]; s_seq[i] = i < call_g->n_seq ? call_g->seq[i] : 0; }\n"
 
                   : "")
@@ -677,14 +686,25 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
       << (call_mode ? "    ROW_TO_CALL();  // the single posterior as printed (GPP) and its arg-max (FGT of shortcut sites)\n" : "")
       << "    LDS_BARRIER();\n"
       << (call_mode ? "    if (call_g->gpp) { STAGE_OUT_CALL(call_g->gpp); }\n" : "    if (single_g) { STAGE_OUT(single_g); }\n")
-      << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n"
-      << "    if (full && !single_fail) {\n"
-      << "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;  // this lane's row in global memory (fp64 input only)\n"
+      << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n";
+    if (chrx_loop)
+      // (as for the sum-product body below) the children's transmission entries depend on the site's chrX bit only: the
+      // body reads them through the wave-uniform pointer tcx (scalar loads) and runs once per chrX value present in the wave
+      s << "    {\n      const int chrx_ = fl >> 1;\n"
+        << "#pragma unroll 1\n"
+        << "      for (int x_ = 0; x_ < 2; ++x_) {\n"
+        << "        const bool mine_ = full && !single_fail && chrx_ == x_;\n"
+        << "        if (__builtin_amdgcn_ballot_w64(mine_) == 0) continue;\n"
+        << "        const double *tcx = tc_g + x_ * 216;\n"
+        << "        if (mine_) {\n";
+    else
+      s << "    if (full && !single_fail) {\n";
+    s << "      const double *lg = lk_g + (site0 + (tid < ns ? tid : 0)) * W3;  // this lane's row in global memory (fp64 input only)\n"
       << "      (void)lg;\n"
       << body
       << "      if (bn_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << (call_mode ? "      ROW_TO_CALL();  // the BN posterior as printed (FPP) and the genotype call\n" : "")
-      << "    }\n";
+      << (chrx_loop ? "        }\n      }\n    }\n" : "    }\n");
     if (prefetch && !early)
       s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
@@ -743,7 +763,7 @@ std::string kernel_shell(const famseq_model &m, const std::string &entry, const 
   return s.str();
 }
 
-std::string elim_source(const famseq_model &m, int variant, bool call_mode) {
+std::string elim_source(const Model &m, int variant, bool call_mode) {
   Graph g;
   std::string why;
   if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);

@@ -42,12 +42,12 @@ struct Shape {
   std::vector<int> upos;             // member -> level in `unrolled` or -1
 };
 
-int kind_of(const famseq_model &m, int p) {
+int kind_of(const Model &m, int p) {
   const bool male = m.gender[p] == 1;
   return m.mother[p] < 0 ? (male ? 0 : 1) : (male ? 2 : 3);
 }
 
-Shape choose_shape(const famseq_model &m, int cap) {
+Shape choose_shape(const Model &m, int cap) {
   const int N = m.n_members;
   std::vector<std::vector<int>> kids(N);
   for (int i = 0; i < N; ++i)
@@ -117,9 +117,14 @@ class Gen {
   // late: the small-pedigree form — the lane's row keeps the input likelihoods (the shell reads them from
   // LDS and turns them into the single posterior only after this body), so the body's scratch slots live
   // behind them (srow = row + W3) and the normalised marginals go to registers q[] instead of the row
-  Gen(const famseq_model &m, const Shape &s, int row_len, int fixed = 0, bool late = false)
+  // scalar_t: the children's transmission entries come from tcx[] (wave-uniform pointer: scalar loads, no LDS
+  // instruction, no VGPR) and the founders' priors are folded into their likelihood slots once per site;
+  // prefetch 1: the entries the innermost loop's tables need are loaded one step ahead (loop-carried SGPRs), 2: so are
+  // that loop's LDS reads — everything the next step's table statements wait for is in flight during this step's block
+  Gen(const Model &m, const Shape &s, int row_len, int fixed = 0, bool late = false, bool scalar_t = false, int prefetch = 0)
       : m_(m), s_(s), nu_((int)s.unrolled.size()), row_len_(row_len), fixed_(fixed), S_(late ? "srow" : "row"),
-        O_(late ? "q" : "row"), outer_(s.outer) {}
+        O_(late ? "q" : "row"), outer_(s.outer), st_(scalar_t && !s.outer.empty()),
+        pre_(scalar_t && fixed < (int)s.outer.size() ? prefetch : 0) {}
 
   // Lanes-per-site mode, last step (the group's first lane, after the column sums): normalise,
   // failure rule (family.cpp:943-954).
@@ -186,9 +191,13 @@ class Gen {
     // and, when they fit, their likelihoods live there instead of in registers, which keeps the
     // unrolled block free of scratch traffic.
     for (int k = 0; k < no; ++k)
+      if (folded(outer_[k]))  // the founder's prior goes into its likelihood once per site (the product the loop would form each time)
+        for (int g = 0; g < 3; ++g)
+          o_ << "      const double pl" << outer_[k] << "_" << g << " = tcf[" << kind_of(m_, outer_[k]) * 27 + 9 * g << "] * l" << outer_[k] << "_" << g << ";\n";
+    for (int k = 0; k < no; ++k)
       for (int g = 0; g < 3; ++g) {
         o_ << "      " << S_ << "[" << 3 * k + g << "] = 0;\n";
-        if (l_in_lds_) o_ << "      " << S_ << "[" << 3 * no + 3 * k + g << "] = l" << outer_[k] << "_" << g << ";\n";
+        if (l_in_lds_) o_ << "      " << S_ << "[" << 3 * no + 3 * k + g << "] = " << l_name(outer_[k], g) << ";\n";
       }
     // The unrolled members' likelihoods are needed only where their tables are rebuilt (outer loop
     // levels).  What is left of the LDS row holds them for the members whose tables sit in the
@@ -279,13 +288,17 @@ class Gen {
   }
 
  private:
-  const famseq_model &m_;
+  const Model &m_;
   const Shape &s_;
   const int nu_;
   const int row_len_;  // doubles in the lane's LDS row (>= 3N, odd)
   const int fixed_;    // outermost looped members whose digit is the lane's (lanes-per-site mode)
   const std::string S_, O_;  // the body's scratch array and where the normalised marginals go
   std::vector<int> outer_;  // looped members, outermost first
+  const bool st_;           // see the constructor
+  const int pre_;
+  std::string prologue_, prefetch_;  // (pre_) before the innermost loop / inside it, between its table statements and the block
+  std::map<std::string, std::string> tq_;  // (pre_) table entry (index text with the innermost digit as '@') -> its loop-carried variable
   std::ostringstream o_;
   int uid_ = 0;
   bool l_in_lds_ = false;
@@ -301,13 +314,39 @@ class Gen {
 
   // table offset of member p's factor for child genotype expression `gc` ("2" or "g7"): literal
   // part + digits of outer parents (runtime, uniform) — unrolled parents are added by the caller
-  std::string t_index(int p, const std::string &gc, int um, int uf) const {
+  // `dm`, `dexpr`: the digit of looped member dm is spelled dexpr instead of g<dm> (the prefetch's next digit)
+  std::string t_index(int p, const std::string &gc, int um, int uf, int dm = -1, const std::string &dexpr = "") const {
+    auto dig = [&](int q) { return q == dm ? dexpr : "g" + num(q); };
     std::string e = num(kind_of(m_, p) * 27) + " + 9 * " + gc;
     if (m_.mother[p] >= 0) {
-      e += um >= 0 ? " + " + num(3 * um) : " + 3 * g" + num(m_.mother[p]);
-      e += uf >= 0 ? " + " + num(uf) : " + g" + num(m_.father[p]);
+      e += um >= 0 ? " + " + num(3 * um) : " + 3 * " + dig(m_.mother[p]);
+      e += uf >= 0 ? " + " + num(uf) : " + " + dig(m_.father[p]);
     }
     return e;
+  }
+  // the table a member's factor entries are read from: the lane's LDS copy (flag-selected: Known picks the founders'
+  // priors), or — scalar_t, children only — the wave-uniform pointer of the body's chrX pass
+  std::string t_tab(int p) const { return st_ && m_.mother[p] >= 0 ? "tcx" : "tcf"; }
+  // founder with its prior folded into the likelihood (scalar_t): pl<p>_<g>, formed once per site
+  bool folded(int p) const { return st_ && m_.mother[p] < 0; }
+  std::string l_name(int p, int g) const { return (folded(p) && outer_pos(p) >= 0 ? "pl" : "l") + num(p) + "_" + num(g); }
+  int inner_pos() const { return (int)outer_.size() - 1; }
+  // (pre_) the loop-carried variable holding table entry `idx` ('@' = the innermost looped member's digit): loaded for
+  // digit 0 ahead of the innermost loop, for the next digit inside it once this digit's table statements are done
+  std::string carried_entry(const std::string &tab, const std::string &idx) {
+    const std::string key = tab + "[" + idx + "]";
+    auto it = tq_.find(key);
+    if (it != tq_.end()) return it->second;
+    const std::string v = "tq" + num((int)tq_.size()), gi = "g" + num(outer_[inner_pos()]);
+    auto spell = [&](const std::string &d) {
+      std::string e = key;
+      for (size_t k; (k = e.find('@')) != std::string::npos;) e.replace(k, 1, d);
+      return e;
+    };
+    prologue_ += "            double " + v + " = " + spell("0") + ";\n";
+    prefetch_ += "              " + v + " = " + spell(gi + "n") + ";\n";
+    tq_[key] = v;
+    return v;
   }
 
   void outer_level(size_t k, const std::string &P, const std::string &acc_parent) {
@@ -319,18 +358,35 @@ class Gen {
     const int no = (int)outer_.size();
     const std::string g = "g" + num(p), ind(6 + 2 * k, ' ');
     const std::string lk_g = l_in_lds_ ? S_ + "[" + num(3 * no + 3 * (int)k) + " + " + g + "]"
-                                       : "(" + g + " == 0 ? l" + num(p) + "_0 : (" + g + " == 1 ? l" + num(p) + "_1 : l" + num(p) + "_2))";
+                                       : "(" + g + " == 0 ? " + l_name(p, 0) + " : (" + g + " == 1 ? " + l_name(p, 1) + " : " + l_name(p, 2) + "))";
+    const bool inner = pre_ > 0 && (int)k == inner_pos();
+    const bool carried_l = inner && pre_ >= 2 && l_in_lds_;
+    std::string f_expr = carried_l ? "lq_" : lk_g;
+    if (!folded(p))
+      f_expr = (inner && m_.mother[p] >= 0 ? carried_entry("tcx", t_index(p, "@", -1, -1, p, "@")) : t_tab(p) + "[" + t_index(p, g, -1, -1) + "]") + " * " + f_expr;
+    if (inner) o_ << prologue_;
+    if (carried_l)  // this loop's own LDS reads, one step ahead: the member's likelihood, its marginal slot
+      o_ << ind << "double lq_ = " << S_ << "[" << 3 * no + 3 * (int)k << "], aq_ = " << S_ << "[" << 3 * (int)k << "];\n";
     if ((int)k < fixed_)
       o_ << ind << "{ const int " << g << " = fx" << k << ";  // one digit per lane of the group\n";
     else
       o_ << "#pragma unroll 1\n"  // keep the walk rolled: an unrolled outer loop triples the block's live state
          << ind << "for (int " << g << " = 0; " << g << " < 3; ++" << g << ") {\n";
-    o_ << ind << "  const double f" << p << " = tcf[" << t_index(p, g, -1, -1) << "] * " << lk_g << ";\n"
+    o_ << ind << "  const double f" << p << " = " << f_expr << ";\n"
        << ind << "  const double P" << p << " = " << P << " * f" << p << ";\n"
        << ind << "  double acc" << p << " = 0;\n"
        << bucket_[k + 1];
+    if (inner) {
+      o_ << ind << "  const int " << g << "n = " << g << " < 2 ? " << g << " + 1 : 2;\n" << prefetch_;
+      if (carried_l) o_ << ind << "  const double lq_n = " << S_ << "[" << 3 * no + 3 * (int)k << " + " << g << "n];\n";
+      o_ << ind << "  __builtin_amdgcn_sched_barrier(0);\n";
+    }
     outer_level(k + 1, "P" + num(p), "acc" + num(p));
-    o_ << ind << "  " << S_ << "[" << 3 * (int)k << " + " << g << "] += acc" << p << ";\n";
+    if (carried_l)
+      o_ << ind << "  " << S_ << "[" << 3 * (int)k << " + " << g << "] = aq_ + acc" << p << ";\n"
+         << ind << "  lq_ = lq_n; aq_ = " << S_ << "[" << 3 * (int)k << " + " << g << "n];\n";
+    else
+      o_ << ind << "  " << S_ << "[" << 3 * (int)k << " + " << g << "] += acc" << p << ";\n";
     if (!acc_parent.empty()) o_ << ind << "  " << acc_parent << " += acc" << p << ";\n";
     o_ << ind << "}\n";
   }
@@ -490,9 +546,25 @@ class Gen {
           std::string suffix;
           if (mu) suffix += "m" + num(gm);
           if (fu) suffix += "f" + num(gf);
-          for (int g = 0; g < 3; ++g)
-            o << ind << "const double w" << p << "_" << g << suffix << " = tcf["
-              << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * " << lk_src(p, g) << ";\n";
+          for (int g = 0; g < 3; ++g) {
+            o << ind << "const double w" << p << "_" << g << suffix << " = ";
+            if (pre_ > 0 && has && wb[k] == innermost) {
+              // rebuilt in the innermost loop: the entry comes from the variable loaded a step ahead, the likelihood — the
+              // same in every step — from a register filled ahead of the loop (prefetch 2) instead of a read per step
+              const int pin = outer_[innermost];
+              o << carried_entry("tcx", t_index(p, num(g), mu ? gm : -1, fu ? gf : -1, pin, "@")) << " * ";
+              const std::string src = lk_src(p, g);
+              if (pre_ >= 2 && src.compare(0, S_.size() + 1, S_ + "[") == 0) {
+                const std::string v = "lq" + num(p) + "_" + num(g);
+                if (prologue_.find(" " + v + " =") == std::string::npos) prologue_ += "            const double " + v + " = " + src + ";\n";
+                o << v << ";\n";
+              } else {
+                o << src << ";\n";
+              }
+            } else {
+              o << t_tab(p) << "[" << t_index(p, num(g), mu ? gm : -1, fu ? gf : -1) << "] * " << lk_src(p, g) << ";\n";
+            }
+          }
         }
       if (lazy_w[k]) continue;  // emitted per digit of the first unrolled member (below)
       bucket_[wb[k] + 1] += o.str();
@@ -505,7 +577,7 @@ class Gen {
         std::ostringstream o;
         const std::string suffix = (mu ? "m" : "f") + num(d);
         for (int g = 0; g < 3; ++g)
-          o << ind << "const double w" << p << "_" << g << suffix << " = tcf[" << t_index(p, num(g), mu ? d : -1, fu ? d : -1)
+          o << ind << "const double w" << p << "_" << g << suffix << " = " << t_tab(p) << "[" << t_index(p, num(g), mu ? d : -1, fu ? d : -1)
             << "] * " << lk_src(p, g) << ";\n";
         lazy0_stmt_[d] += o.str();
       }
@@ -687,7 +759,7 @@ class Gen {
 
 }  // namespace
 
-std::string enumgen_describe(const famseq_model &m, int variant) {
+std::string enumgen_describe(const Model &m, int variant) {
   int cap = (variant >= 0 && variant < 2) ? 7 : 6;  // kEnumVariants; unknown yet (-1): the 6-member form
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);
   const Shape s = choose_shape(m, cap);
@@ -707,7 +779,7 @@ std::string enumgen_describe(const famseq_model &m, int variant) {
 // the ten-member kernel: 24 of them instead of 108 bytes of scratch per lane, an LDS row of 43 instead of 37 doubles
 // (a quarter of the lanes per CU: no likelihood is re-read from global memory any more), 10.21 -> 9.78 ms per 4 M sites
 // (profiles/r02c/exp_block_sizes_*.txt).  The lanes-per-site forms keep wide workgroups: a site's 81 lanes span waves.
-int enumgen_block_threads(const famseq_model &m, int group_digits) {
+int enumgen_block_threads(const Model &m, int group_digits) {
   if (const char *e = std::getenv("FAMSEQ_LANE_BT")) return std::atoi(e);  // tuning aid
   if (group_digits == 0) return 64;
   return m.n_members <= 10 ? 256 : 128;
@@ -715,17 +787,17 @@ int enumgen_block_threads(const famseq_model &m, int group_digits) {
 
 // (asked of the call-path form: its LDS row has less room than the plain form's, so it may re-read members
 // the plain form keeps in LDS — and it is the form that can be fed packed PLs, with no fp64 rows to read)
-bool enumgen_reads_global_rows(const famseq_model &m, int variant) {
+bool enumgen_reads_global_rows(const Model &m, int variant) {
   return enumgen_source(m, variant, 0, /*call_mode=*/true).find("lg[") != std::string::npos;
 }
 
-int enumgen_max_group_digits(const famseq_model &m) {
+int enumgen_max_group_digits(const Model &m) {
   int cap = 6;
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);
   return std::min<int>(kEnumMaxGroupDigits, (int)choose_shape(m, cap).outer.size());
 }
 
-int enumgen_sites_per_chunk(const famseq_model &m, int group_digits) {
+int enumgen_sites_per_chunk(const Model &m, int group_digits) {
   int g = 1;
   for (int k = 0; k < group_digits; ++k) g *= 3;
   return enumgen_block_threads(m, group_digits) / g;
@@ -740,7 +812,7 @@ namespace {
 // latency drops by G and G times as many lanes are busy, which is what a batch too small to give
 // every lane of the chip a site of its own needs (one lane per site: 0.17 ms for anything up to 131 k
 // 10-member sites).  I/O is a plain strided walk — this shell never sees a large batch.
-std::string grouped_shell(const famseq_model &m, const std::string &comment, const std::string &body, const std::string &reduce,
+std::string grouped_shell(const Model &m, const std::string &comment, const std::string &body, const std::string &reduce,
                           int bt, int min_waves, bool fence_single, int row_doubles, int group) {
   const int N = m.n_members, W3 = 3 * N, ROW = (row_doubles > 0 ? row_doubles : W3) | 1;
   std::ostringstream s;
@@ -811,7 +883,7 @@ std::string grouped_shell(const famseq_model &m, const std::string &comment, con
 
 }  // namespace
 
-std::string enumgen_source(const famseq_model &m, int variant, int group_digits, bool call_mode) {
+std::string enumgen_source(const Model &m, int variant, int group_digits, bool call_mode) {
   int cap = (group_digits == 0 && variant < 2) ? 7 : 6;  // see kEnumVariants
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);  // tuning aid
   const Shape s = choose_shape(m, cap);
@@ -830,7 +902,7 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
     const int used = 6 * (int)s.outer.size() <= row_len ? 6 * (int)s.outer.size() : 3 * (int)s.outer.size();
     const int want = (used + 3 * looped_tables) | 1;
     // odd, two workgroups per CU (the call-path form also keeps a byte per member and lane, and two small tables)
-    const int fit = ((160 * 1024 / 2 - 432 * 8 - (call_mode ? bt * m.n_members + 256 : 0)) / (bt * 8) - 1) | 1;
+    const int fit = ((160 * 1024 / 2 - 432 * 8 - (call_mode ? bt * m.n_members + 256 + 2064 : 0)) / (bt * 8) - 1) | 1;
     if (want > row_len) row_len = std::min(want, std::max(row_len, fit));
   }
   // An experiment that is OFF (FAMSEQ_LANE_LATE=1 turns it on): the sum-product kernel's order of phases for
@@ -847,7 +919,7 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
     int looped_tables = 0;
     for (int p : s.unrolled)
       if (m.mother[p] >= 0 && (s.upos[m.mother[p]] < 0 || s.upos[m.father[p]] < 0)) ++looped_tables;
-    const int fit = ((160 * 1024 / 2 - 432 * 8 - (call_mode ? bt * m.n_members + 256 : 0)) / (bt * 8) - 1) | 1;
+    const int fit = ((160 * 1024 / 2 - 432 * 8 - (call_mode ? bt * m.n_members + 256 + 2064 : 0)) / (bt * 8) - 1) | 1;
     const int w3 = 3 * m.n_members, room = fit - w3;
     if (room < 3 * (int)s.outer.size()) late = false;  // not even the looped members' accumulators fit behind the row
     else {
@@ -866,7 +938,18 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
            " unrolled members, variant " + std::to_string(variant);
   int min_waves = group_digits == 0 ? 1 : bt / 128;
   if (const char *e = std::getenv("FAMSEQ_LANE_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
-  Gen gen(m, s, late ? std::max(scratch_len, 1) : row_len, group_digits, late);
+  // Transmission entries through scalar loads, and the innermost loop's loads one step ahead (see Gen): the one-lane-per-site
+  // forms of pedigrees that have looped members; the lanes-per-site forms keep the per-lane LDS table.  Round 3, measured
+  // with tools/kernel_bench on one box (profiles/r03a/exp_scalar_tables.txt): ten members 10.40 -> 10.13-10.20 ms per 4 M sites,
+  // fifteen 139.2 -> 138.4 ms per 262 k; the innermost loop loses 36 of its 39 LDS reads and 10 of its 11 waits (885 -> 881
+  // instructions per 729 configurations) — the waits were a small part of what one wave per SIMD loses: at 1.21 instructions
+  // per configuration in that loop and 1.33 overall the kernel runs at the issue rate a single wave sustains.
+  bool scalar_t = true;
+  int prefetch = 2;
+  if (const char *e = std::getenv("FAMSEQ_LANE_ST")) scalar_t = std::atoi(e) != 0;  // tuning aid
+  if (const char *e = std::getenv("FAMSEQ_LANE_PRE")) prefetch = std::atoi(e);     // tuning aid: 0 none, 1 table entries, 2 and LDS reads
+  scalar_t = scalar_t && group_digits == 0 && !late && !s.outer.empty();
+  Gen gen(m, s, late ? std::max(scratch_len, 1) : row_len, group_digits, late, scalar_t, prefetch);
   if (call_mode) what += ", call path";
   if (late)  // regs_l = false: the shell's compute-first flow; variant 0 / 1 as below
     return kernel_shell(m, "famseq_enum_lane", what + ", compute-first shell", gen.body(), bt, min_waves, /*regs_l=*/false, (variant & 1) != 0,
@@ -880,7 +963,7 @@ std::string enumgen_source(const famseq_model &m, int variant, int group_digits,
   // regs_l: LDS-resident likelihoods measured 17% slower.  variant 0: the members of the single
   // posterior overlap, 1: fenced one from the other (fewer registers)
   return kernel_shell(m, "famseq_enum_lane", what, gen.body(), bt, min_waves, /*regs_l=*/true, fence_single,
-                      /*chrx_loop=*/false, row_len, call_mode);
+                      /*chrx_loop=*/scalar_t, row_len, call_mode);
 }
 
 }  // namespace famseq

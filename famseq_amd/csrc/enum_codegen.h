@@ -5,6 +5,7 @@
 #include <string>
 
 #include "famseq_hip.h"
+#include "model.h"
 
 namespace famseq {
 
@@ -18,16 +19,16 @@ constexpr int kEnumVariants = 4;
 // group_digits = d > 0: lanes-per-site mode for small batches — 3^d consecutive lanes share a site, each
 // taking one combination of the d outermost looped members' digits (d <= enumgen_max_group_digits)
 constexpr int kEnumMaxGroupDigits = 4;
-std::string enumgen_source(const famseq_model &m, int variant, int group_digits = 0, bool call_mode = false);
-int enumgen_max_group_digits(const famseq_model &m);
+std::string enumgen_source(const Model &m, int variant, int group_digits = 0, bool call_mode = false);
+int enumgen_max_group_digits(const Model &m);
 // true when the call-path form of the one-lane-per-site kernel re-reads some members' likelihoods from the
 // fp64 rows in global memory inside its loops (wide pedigrees whose LDS row cannot hold them): such a kernel
 // must be given fp64 input (lk_g non-null), never packed PLs
-bool enumgen_reads_global_rows(const famseq_model &m, int variant);
-int enumgen_sites_per_chunk(const famseq_model &m, int group_digits);  // sites a workgroup handles per chunk
-int enumgen_block_threads(const famseq_model &m, int group_digits = 0);
+bool enumgen_reads_global_rows(const Model &m, int variant);
+int enumgen_sites_per_chunk(const Model &m, int group_digits);  // sites a workgroup handles per chunk
+int enumgen_block_threads(const Model &m, int group_digits = 0);
 // One-line description of the lane kernel's tiling (which members are looped / unrolled).
-std::string enumgen_describe(const famseq_model &m, int variant = -1);  // shape of the one-lane-per-site kernel of that variant
+std::string enumgen_describe(const Model &m, int variant = -1);  // shape of the one-lane-per-site kernel of that variant
 
 }  // namespace famseq
 #endif

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <charconv>
 #include <chrono>
@@ -582,9 +583,23 @@ size_t batch_capacity() {
 
 // ---- model + ctx ---------------------------------------------------------------------------
 
-famseq_ctx *make_ctx(const Options &o, const Ped &ped, const vector<uint8_t> &sequenced, famseq_model &m) {
-  const int rc = famseq_model_init(&m, ped.n(), ped.id.data(), ped.mid.data(), ped.fid.data(), ped.gender.data(),
-                                   sequenced.data(), o.mrate, o.lrc);
+// The size-independent model of the ABI (famseq_pedigree) with the arrays it points into: the reference's drivers
+// take a PED file of any length (readPed, file.cpp:24-62), and so does its -method 2.
+struct CliModel {
+  famseq_pedigree p;
+  vector<int32_t> mo, fa;
+  vector<uint8_t> seq;
+  int init(const Ped &ped, const vector<uint8_t> &sequenced, double mrate, double lrc) {
+    mo.assign(ped.n(), -1);
+    fa.assign(ped.n(), -1);
+    seq = sequenced;
+    return famseq_pedigree_init(&p, ped.n(), ped.id.data(), ped.mid.data(), ped.fid.data(), ped.gender.data(), seq.data(), mrate,
+                                lrc, mo.data(), fa.data());
+  }
+};
+
+famseq_ctx *make_ctx(const Options &o, const Ped &ped, const vector<uint8_t> &sequenced, CliModel &m) {
+  const int rc = m.init(ped, sequenced, o.mrate, o.lrc);
   if (rc == FAMSEQ_E_PED_HALF) std::cout << "This is not a fulfill family. Please check the ped file." << std::endl;
   if (rc == FAMSEQ_E_PED_SEX) std::cerr << "A mother is not a female or a father is not a male in the ped file." << std::endl;
   if (rc != 0) {
@@ -594,13 +609,18 @@ famseq_ctx *make_ctx(const Options &o, const Ped &ped, const vector<uint8_t> &se
   auto put = [](double *dst, const vector<double> &src) {
     if (src.size() == 3) std::copy(src.begin(), src.end(), dst);
   };
-  put(m.genoProbN, o.gN);
-  put(m.genoProbK, o.gK);
-  put(m.genoProbXN, o.gXN);
-  put(m.genoProbXK, o.gXK);
+  put(m.p.genoProbN, o.gN);
+  put(m.p.genoProbK, o.gK);
+  put(m.p.genoProbXN, o.gXN);
+  put(m.p.genoProbXK, o.gXK);
   const char *dev = std::getenv("FAMSEQ_DEVICE");
   char err[512] = {0};
-  famseq_ctx *ctx = famseq_create(&m, dev ? std::atoi(dev) : 0, err, sizeof err);
+  if (ped.n() > FAMSEQ_MAX_MEMBERS && o.method != 2) {  // the reference's own advice for -method 1 is "family size less than seven"
+    std::cout << "The pedigree has " << ped.n() << " members: -method 1 enumerates 3^N joint genotypes and serves up to "
+              << FAMSEQ_MAX_MEMBERS << ". Use -method 2 for this pedigree." << std::endl;
+    return nullptr;
+  }
+  famseq_ctx *ctx = famseq_create_pedigree(&m.p, dev ? std::atoi(dev) : 0, err, sizeof err);
   if (!ctx) {
     std::cerr << "Cannot create the GPU context: " << err << std::endl;
     return nullptr;
@@ -817,15 +837,14 @@ bool run_pl(const Options &o, const Ped &ped) {
     }
   }
 
-  famseq_model m;
+  CliModel m;
   famseq_ctx *ctx = nullptr;
   if (o.unpack_mode) {  // only the header needs the model's priors
-    if (famseq_model_init(&m, ped.n(), ped.id.data(), ped.mid.data(), ped.fid.data(), ped.gender.data(), sequenced.data(),
-                          o.mrate, o.lrc) != 0) {
+    if (m.init(ped, sequenced, o.mrate, o.lrc) != 0) {
       std::cout << "Cannot initiate family. Please check ped file." << std::endl;
       return false;
     }
-    if (o.gN.size() == 3) std::copy(o.gN.begin(), o.gN.end(), m.genoProbN);
+    if (o.gN.size() == 3) std::copy(o.gN.begin(), o.gN.end(), m.p.genoProbN);
   } else {
     const double t0 = now_s();
     ctx = make_ctx(o, ped, sequenced, m);
@@ -852,7 +871,7 @@ bool run_pl(const Options &o, const Ped &ped) {
             "calculated by FamSeqPro\">" << std::endl;
     fout << "##FORMAT=<ID=FGT,Number=1,Type=String,Description=\"Genotype called by FamSeqPro\">" << std::endl;
     fout << "##FS mutation rate=" << o.mrate << " " << std::endl;
-    fout << "##FS genotype frequency in pupulation: "; put_triple(fout, m.genoProbN); fout << std::endl;
+    fout << "##FS genotype frequency in pupulation: "; put_triple(fout, m.p.genoProbN); fout << std::endl;
     fout << "#FORMAT\t";
     for (uint32_t c : seq_cols) fout << names[c] << '\t';
     fout << std::endl;
@@ -1091,6 +1110,9 @@ struct LineSource {
         return true;
       }
     }
+    // Not a regular file (a pipe, /dev/stdin) or one that cannot be mapped: read whole into memory — the parsed items
+    // point into the input text until their block is written, which a bounded read-ahead buffer would have to guarantee
+    // block by block.  A piped VCF therefore needs memory of its size; give large inputs as files (the usage text says so).
     char buf[1 << 16];
     ssize_t r;
     while ((r = ::read(fd, buf, sizeof buf)) > 0) owned.append(buf, size_t(r));
@@ -1125,19 +1147,18 @@ bool run_vcf(const Options &o, const Ped &ped) {
     std::cout << "Cannot open " << o.vcf_files[0] << std::endl;
     return false;
   }
-  famseq_model m;
+  CliModel m;
   // defaults needed for the header before the ctx exists
   {
     vector<uint8_t> all(ped.n(), 1);
-    if (famseq_model_init(&m, ped.n(), ped.id.data(), ped.mid.data(), ped.fid.data(), ped.gender.data(), all.data(),
-                          o.mrate, o.lrc) != 0) {
+    if (m.init(ped, all, o.mrate, o.lrc) != 0) {
       std::cout << "Cannot initiate family. Please check ped file." << std::endl << "Cannot set family." << std::endl;
       return false;
     }
-    if (o.gN.size() == 3) std::copy(o.gN.begin(), o.gN.end(), m.genoProbN);
-    if (o.gK.size() == 3) std::copy(o.gK.begin(), o.gK.end(), m.genoProbK);
-    if (o.gXN.size() == 3) std::copy(o.gXN.begin(), o.gXN.end(), m.genoProbXN);
-    if (o.gXK.size() == 3) std::copy(o.gXK.begin(), o.gXK.end(), m.genoProbXK);
+    if (o.gN.size() == 3) std::copy(o.gN.begin(), o.gN.end(), m.p.genoProbN);
+    if (o.gK.size() == 3) std::copy(o.gK.begin(), o.gK.end(), m.p.genoProbK);
+    if (o.gXN.size() == 3) std::copy(o.gXN.begin(), o.gXN.end(), m.p.genoProbXN);
+    if (o.gXK.size() == 3) std::copy(o.gXK.begin(), o.gXK.end(), m.p.genoProbXK);
   }
   // pack mode writes a binary file: the text header goes nowhere
   std::ofstream fout;
@@ -1153,10 +1174,10 @@ bool run_vcf(const Options &o, const Ped &ped) {
   };
   auto fs_info = [&] {
     fout << "##FS mutation rate=" << o.mrate << " " << std::endl;
-    fout << "##FS genotype frequency in pupulation (Rare): "; put_triple(fout, m.genoProbN); fout << std::endl;
-    fout << "##FS genotype frequency in population (Common): "; put_triple(fout, m.genoProbK); fout << std::endl;
-    fout << "##FS genotype frequency for chromosome X of male in population (Rare): "; put_triple(fout, m.genoProbXN); fout << std::endl;
-    fout << "##FS genotype frequency for chromosome X of male in population (Common): "; put_triple(fout, m.genoProbXK); fout << std::endl;
+    fout << "##FS genotype frequency in pupulation (Rare): "; put_triple(fout, m.p.genoProbN); fout << std::endl;
+    fout << "##FS genotype frequency in population (Common): "; put_triple(fout, m.p.genoProbK); fout << std::endl;
+    fout << "##FS genotype frequency for chromosome X of male in population (Rare): "; put_triple(fout, m.p.genoProbXN); fout << std::endl;
+    fout << "##FS genotype frequency for chromosome X of male in population (Common): "; put_triple(fout, m.p.genoProbXK); fout << std::endl;
   };
   string title;
   std::string_view line;
@@ -1242,10 +1263,22 @@ bool run_vcf(const Options &o, const Ped &ped) {
       std::cout << "Cannot write " << o.out_file << " (or no sample of the vcf file is in the ped file)." << std::endl;
       return false;
     }
-  } else {
-    ctx = make_ctx(o, ped, sequenced, m);
-    if (!ctx) return false;
+  } else if (seq_cols.empty()) {  // nothing to compute and nothing to print per sample: say so instead of walking the file
+    std::cout << "No sample of the vcf file is in the ped file (the names in the ped file's fifth column must match the vcf header)." << std::endl;
+    return false;
   }
+  // HIP start-up (runtime initialisation, context, streams, code objects: about a quarter of a second) runs on its own
+  // thread while this one cuts and parses the first block(s); the flusher thread, the first to need the context, waits for it.
+  // Until it is there the blocks are parsed into ordinary memory (pinned buffers need the runtime) and copied over — 6 bytes
+  // per sample and site — once it is.
+  std::atomic<bool> hip_up{false};
+  std::future<famseq_ctx *> ctx_future;
+  if (!o.pack_mode)
+    ctx_future = std::async(std::launch::async, [&] {
+      famseq_ctx *c = make_ctx(o, ped, sequenced, m);
+      hip_up = true;
+      return c;
+    });
   const PlTable pl;
   const size_t n_seq = seq_cols.size(), N3 = size_t(3) * ped.n();
 
@@ -1379,7 +1412,8 @@ bool run_vcf(const Options &o, const Ped &ped) {
     int n_parts = 0;
     size_t n_sites = 0;  // sites of the batch: the block's lines, or (large pedigrees) its sites moved together
     bool packed = true;
-    vector<uint16_t> pk_pl;     // pack mode: the block's arrays live here, nothing is pinned
+    bool staged = false;        // parsed into pk_pl / pk_flags because the HIP runtime was not up yet: the flusher copies them over
+    vector<uint16_t> pk_pl;     // pack mode (and staged blocks): the block's arrays live here, nothing is pinned
     vector<uint8_t> pk_flags;
     PlBatch io;          // pinned: pl + flags in, gpp / fpp / fgt / status out
     vector<double> lk;   // fp64 input, only for a block with a non-integer PL/GL field
@@ -1388,7 +1422,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
   bool ok = true;
   for (Slot &sl : slots) sl.parts.resize(n_threads), sl.text.resize(n_threads);
 
-  double t_lines = 0, t_parse = 0, t_gather = 0, t_stall = 0, t_gpu = 0, t_format = 0, t_write = 0;
+  double t_lines = 0, t_parse = 0, t_gather = 0, t_stall = 0, t_gpu = 0, t_format = 0, t_write = 0, t_ctx_wait = 0;
   int compact_from = 12;  // members from which a block's sites are moved together before the GPU call (below)
   if (const char *e = std::getenv("FAMSEQ_COMPACT_FROM")) compact_from = std::atoi(e);  // test aid
   Channel to_flusher, to_driver;
@@ -1399,6 +1433,27 @@ bool run_vcf(const Options &o, const Ped &ped) {
       if (i < 0) break;
       Slot &sl = slots[i];
       const size_t k = n_seq;
+      if (!ctx && ctx_future.valid()) {  // the first block: the context has been coming up meanwhile
+        const double tw = now_s();
+        ctx = ctx_future.get();
+        t_ctx_wait = now_s() - tw;
+        if (!ctx) flush_ok = false;
+      }
+      if (sl.staged && flush_ok) {  // parsed before the runtime was up: into the pinned arrays now
+        const size_t nl_ = sl.pk_flags.size();
+        if (sl.io.cap < nl_) {
+          sl.io.release();
+          sl.io = PlBatch();
+          if (!sl.io.alloc(nl_, std::max<size_t>(n_seq, 1))) {
+            std::cerr << "cannot allocate pinned host buffers" << std::endl;
+            flush_ok = false;
+          }
+        }
+        if (flush_ok) {
+          std::memcpy(sl.io.pl, sl.pk_pl.data(), nl_ * 6 * n_seq);
+          std::memcpy(sl.io.flags, sl.pk_flags.data(), nl_);
+        }
+      }
       const double t0 = now_s();
       if (sl.n_sites > 0 && flush_ok) {
         const int rc = famseq_bn_call_batch(ctx, (int64_t)sl.n_sites, sl.packed ? nullptr : sl.lk.data(), sl.packed ? sl.io.pl : nullptr,
@@ -1493,7 +1548,8 @@ bool run_vcf(const Options &o, const Ped &ped) {
     sl.n_parts = nl < 2048 ? 1 : (int)n_threads;
     double t2 = now_s();
     t_lines += t2 - t1;
-    if (o.pack_mode) {
+    sl.staged = !o.pack_mode && !hip_up;
+    if (o.pack_mode || sl.staged) {
       sl.pk_pl.resize(nl * 3 * n_seq), sl.pk_flags.resize(nl);
     } else if (sl.io.cap < nl) {  // pinned, sized by the first block (a short file does not pay for 65,536 sites)
       sl.io.release();
@@ -1505,8 +1561,8 @@ bool run_vcf(const Options &o, const Ped &ped) {
         break;
       }
     }
-    uint16_t *const pl_arr = o.pack_mode ? sl.pk_pl.data() : sl.io.pl;
-    uint8_t *const flags_arr = o.pack_mode ? sl.pk_flags.data() : sl.io.flags;
+    uint16_t *const pl_arr = o.pack_mode || sl.staged ? sl.pk_pl.data() : sl.io.pl;
+    uint8_t *const flags_arr = o.pack_mode || sl.staged ? sl.pk_flags.data() : sl.io.flags;
     on_threads(sl.n_parts, [&](int t) {
       Part &pt = sl.parts[t];
       pt.clear();
@@ -1591,11 +1647,12 @@ bool run_vcf(const Options &o, const Ped &ped) {
   }
   to_flusher.put(-1);
   flusher.join();
-  ok = ok && flush_ok;
+  if (!ctx && ctx_future.valid()) ctx = ctx_future.get();  // a file without a single data line: nobody asked for it yet
+  ok = ok && flush_ok && (o.pack_mode || ctx);
   if (std::getenv("FAMSEQ_TIMING") && !o.pack_mode)
     std::cerr << "FamSeq vcf: loop " << now_s() - t_begin << " s; this thread: cutting lines " << t_lines << ", parsing " << t_parse
               << ", fp64 rows / pack records " << t_gather << ", waiting for the flusher " << t_stall << "; flusher thread: GPU calls " << t_gpu
-              << ", formatting " << t_format << ", writing " << t_write << std::endl;
+              << ", formatting " << t_format << ", writing " << t_write << ", waiting for the context " << t_ctx_wait << std::endl;
   if (!o.pack_mode)
     for (Slot &sl : slots) sl.io.release();
   if (o.pack_mode) {
@@ -1629,7 +1686,7 @@ bool run_lk(const Options &o, const Ped &ped) {
         sequenced[j] = 1;
         break;
       }
-  famseq_model m;
+  CliModel m;
   famseq_ctx *ctx = make_ctx(o, ped, sequenced, m);
   if (!ctx) return false;
   std::ofstream fout(o.out_file.c_str());
@@ -1639,7 +1696,7 @@ bool run_lk(const Options &o, const Ped &ped) {
           "calculated by FamSeqPro\">" << std::endl;
   fout << "##FORMAT=<ID=FGT,Number=1,Type=String,Description=\"Genotype called by FamSeqPro\">" << std::endl;
   fout << "##FS mutation rate=" << o.mrate << " " << std::endl;
-  fout << "##FS genotype frequency in pupulation: "; put_triple(fout, m.genoProbN); fout << std::endl;
+  fout << "##FS genotype frequency in pupulation: "; put_triple(fout, m.p.genoProbN); fout << std::endl;
   vector<int> seq_cols, seq_members;
   fout << "#FORMAT\t";
   for (size_t i = 0; i < head.size(); i++)
@@ -1695,7 +1752,7 @@ bool run_tune(const Options &o, const Ped &ped) {
   for (size_t i = 9; i < head.size(); i++)
     for (int j = 0; j < ped.n(); j++)
       if (head[i] == ped.name[j]) sequenced[j] = 1;
-  famseq_model m;
+  CliModel m;
   famseq_ctx *ctx = make_ctx(o, ped, sequenced, m);
   if (!ctx) return false;
   const int rc = famseq_set_option(ctx, "tune", 1);

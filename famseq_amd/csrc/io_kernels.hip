@@ -12,8 +12,8 @@
 //                column order (get_postProb(true), family.cpp:584-596).
 // Both are one-element-per-lane streaming kernels (coalesced 8 B/lane).  A workgroup walks tiles of
 // kTileSites sites; inside a tile the element index is a 16-bit number, so site / member / genotype
-// come from two multiply-shift divisions (exact for n < 2^16, divisors <= 60: the launchers check
-// 3 * members <= 60) instead of the 64-bit integer divisions a flat index over n_sites * W3 costs.
+// come from two multiply-shift divisions (exact for n < 2^16, divisors <= 510: the launchers check
+// members <= 170) instead of the 64-bit integer divisions a flat index over n_sites * W3 costs.
 // phred_call is bound by its two fp64 logarithms per element (VALU; phred_src.h), unpack_pl16 by HBM.
 // Batches served by the generated kernels do both inside the posterior kernel (elim_codegen.cpp kCallHelpers);
 // these two remain for the compiled-in team kernel and the lanes-per-site mode.
@@ -25,9 +25,10 @@ namespace famseq {
 
 namespace {
 
-constexpr int kTileSites = 128;  // 128 * 60 = 7680 elements per tile (must stay < 2^16)
+constexpr int kTileSites = 128;  // 128 * 3 * kMaxIoMembers = 65280 elements per tile (must stay < 2^16)
+constexpr int kMaxIoMembers = 170;  // r / 3 as (r * 171) >> 9 is exact for r < 512
 
-// n / d for n < 2^16, 1 <= d <= 60: the high word of n * (2^32 / d + 1) (error < n / 2^32 < 1 / d)
+// n / d for n < 2^16, 1 <= d <= 510: the high word of n * (2^32 / d + 1) (error < n / 2^32 < 1 / d)
 __device__ __forceinline__ unsigned div_small(unsigned n, unsigned magic) { return __umulhi(n, magic); }
 __host__ __device__ constexpr unsigned magic_for(unsigned d) { return 0xFFFFFFFFu / d + 1; }
 
@@ -64,9 +65,15 @@ __global__ __launch_bounds__(256) void unpack_pl16_kernel(const uint16_t *__rest
 #define FS_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
 #define FS_IS_POS_FINITE(x) __builtin_amdgcn_class(x, 0x180)
 #define FS_KEEP_BRANCH() asm volatile("" ::: "memory")
+#define FS_HI32(x) __double2hiint(x)
+typedef double fs_v2d __attribute__((ext_vector_type(2)));
 #define FS_PHRED_DEF(...) __VA_ARGS__
 #include "phred_src.h"
-__device__ __forceinline__ double phred(double p) { return fs_phred(p); }
+#define FS_TAB_ROW(a, b) a, b,
+__device__ const double fs_logtab[258] = {
+#include "phred_tab.h"
+};
+#undef FS_TAB_ROW
 
 __global__ __launch_bounds__(256) void phred_call_kernel(const double *__restrict__ post, const double *__restrict__ single,
                                                          const uint8_t *__restrict__ status,
@@ -75,6 +82,9 @@ __global__ __launch_bounds__(256) void phred_call_kernel(const double *__restric
                                                          int8_t *__restrict__ fgt) {
   const unsigned w3 = 3 * n_seq, mw3 = magic_for(w3);
   const double nan = __builtin_nan("");
+  __shared__ __attribute__((aligned(16))) double s_lt[258];  // fs_phred's table: one 16-byte LDS read per logarithm
+  for (int i = threadIdx.x; i < 258; i += 256) s_lt[i] = fs_logtab[i];
+  __syncthreads();
   const long tiles = (n_sites + kTileSites - 1) / kTileSites;
   for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
     const long site0 = t * kTileSites;
@@ -85,8 +95,8 @@ __global__ __launch_bounds__(256) void phred_call_kernel(const double *__restric
       const unsigned s = div_small(e, mw3), r = e - s * w3, k = (r * 171) >> 9, g = r - 3 * k;
       const unsigned src = (s * n_members + seq_members[k]) * 3;
       const int st = status[site0 + s] & 3;
-      gpp[site0 * w3 + e] = st == 1 ? nan : phred(singlet[src + g]);
-      fpp[site0 * w3 + e] = st != 0 ? nan : phred(postt[src + g]);
+      gpp[site0 * w3 + e] = st == 1 ? nan : fs_phred(singlet[src + g], s_lt);
+      fpp[site0 * w3 + e] = st != 0 ? nan : fs_phred(postt[src + g], s_lt);
       if (g == 0) {
         int8_t pick = -1;
         if (st == 0) {
@@ -128,7 +138,7 @@ int grid_for(long n_sites) {
 hipError_t launch_unpack_pl16(const uint16_t *d_pl, const int32_t *d_col_of_member, const double *d_lut, int n_members,
                               int n_seq, int64_t n_sites, double *d_lk, hipStream_t stream) {
   if (n_sites <= 0) return hipSuccess;
-  if (n_members < 1 || n_members > 20) return hipErrorInvalidValue;  // div_small's range
+  if (n_members < 1 || n_members > kMaxIoMembers) return hipErrorInvalidValue;  // div_small's range
   hipLaunchKernelGGL(unpack_pl16_kernel, dim3(grid_for(n_sites)), dim3(256), 0, stream, d_pl,
                      d_col_of_member, d_lut, n_members, n_seq, (long)n_sites, d_lk);
   return hipGetLastError();
@@ -145,7 +155,7 @@ hipError_t launch_phred_call(const double *d_post, const double *d_single, const
                              const int32_t *d_seq_members, int n_members, int n_seq, int64_t n_sites, double *d_gpp,
                              double *d_fpp, int8_t *d_fgt, hipStream_t stream) {
   if (n_sites <= 0 || n_seq <= 0) return hipSuccess;
-  if (n_seq > 20 || n_members > 20) return hipErrorInvalidValue;  // div_small's range
+  if (n_seq > kMaxIoMembers || n_members > kMaxIoMembers) return hipErrorInvalidValue;  // div_small's range
   hipLaunchKernelGGL(phred_call_kernel, dim3(grid_for(n_sites)), dim3(256), 0, stream, d_post, d_single,
                      d_status, d_seq_members, n_members, n_seq, (long)n_sites, d_gpp, d_fpp, d_fgt);
   return hipGetLastError();

@@ -28,9 +28,11 @@ uint64_t fnv1a(const std::string &s) {
   return h;
 }
 
+// a code object that is there AND has content (a zero-length file — an interrupted writer, a test placeholder —
+// is no cache hit)
 bool exists(const std::string &p) {
   struct stat st;
-  return ::stat(p.c_str(), &st) == 0;
+  return ::stat(p.c_str(), &st) == 0 && st.st_size > 0;
 }
 
 bool writable_dir(const std::string &d) {
@@ -204,13 +206,13 @@ std::string jit_compile(const std::string &source, int *scratch_bytes, bool note
       }
     }
   }
-  if (std::getenv("FAMSEQ_JIT_SOURCE_ONLY")) {
-    // test aid (tests/test_generated_host.py compiles the generated SOURCE for the host): keep the source,
-    // leave an empty placeholder where the code object would be, do not run the compiler.  A placeholder
-    // never loads (hipModuleLoad fails loudly), so this cannot turn into a silent product path.
+  if (std::getenv("FAMSEQ_JIT_SOURCE_ONLY") && std::getenv("FAMSEQ_KERNEL_CACHE")) {
+    // test aid (tests/test_generated_host.py compiles the generated SOURCE for the host), honoured only together with
+    // an explicit scratch cache: keep the source and a resource note, do not run the compiler.  No code object is
+    // written (not even an empty one: nothing a later process could take for a cache hit); the path returned names
+    // where it would be, and loading it fails loudly, so this cannot turn into a silent product path.
     std::ofstream((dir + "/" + name + ".hip").c_str()) << source;
     std::ofstream((dir + "/" + name + ".res").c_str()) << 0 << "\n";
-    std::ofstream(obj.c_str()).flush();
     if (scratch_bytes) *scratch_bytes = 0;
     return obj;
   }
@@ -283,7 +285,6 @@ std::string jit_pick_variant(const std::function<std::string(int)> &generate, in
   int best_scratch = -1, best_i = 0;
   first = std::max(0, std::min(first, n_variants - 1));
   if (const char *e = std::getenv("FAMSEQ_VARIANT_MIN")) first = std::max(0, std::min(std::atoi(e), n_variants - 1));  // tuning aid
-  std::vector<std::string> rejected;  // code objects of variants that lost: only their resource notes are kept
   std::string best_obj;
   for (int v = first; v < n_variants; ++v) {
     std::string src = generate(v);
@@ -291,20 +292,16 @@ std::string jit_pick_variant(const std::function<std::string(int)> &generate, in
     const std::string obj = jit_compile(src, &scratch, /*note_suffices=*/true);
     if (scratch < 0) scratch = 0;  // an object without a note (older cache): take it as it is
     if (best.empty() || scratch < best_scratch) {
-      if (!best_obj.empty()) rejected.push_back(best_obj);
       best.swap(src);
       best_obj = obj;
       best_scratch = scratch;
       best_i = v;
-    } else if (!obj.empty()) {
-      rejected.push_back(obj);
     }
     if (best_scratch <= kSpillTolerance) break;
   }
-  // a cache directory holds one code object per kernel, not one per variant tried (the notes are tiny and
-  // spare the next process the compilations); shipped (read-only) directories are left alone
-  for (const std::string &o : rejected)
-    if (!o.empty() && o != best_obj) (void)::unlink(o.c_str());
+  // (The objects of variants that lost stay where they are: another process or rank sharing the cache may just have
+  // been handed one of those paths by jit_compile, and deleting it under that process turned into a failed
+  // hipModuleLoad and a context stuck on the fallback kernel.  Their resource notes spare later contests the compilations.)
   if (picked) *picked = best_i;
   return best;
 }
@@ -319,12 +316,14 @@ std::string pick_name(const std::string &key_source) {
 
 int jit_read_pick(const std::string &key_source) {
   const std::string name = pick_name(key_source);
+  // where jit_write_pick writes first — a local "tune" overrides the picks shipped next to a read-only library —,
+  // then the shipped directory (an explicit cache: that directory only)
   std::vector<std::string> dirs;
-  if (!std::getenv("FAMSEQ_KERNEL_CACHE")) dirs.push_back(lib_dir() + "/kernels");  // (an explicit cache: that directory only)
   try {
     dirs.push_back(cache_dir());
   } catch (const std::exception &) {
   }
+  if (!std::getenv("FAMSEQ_KERNEL_CACHE") && (dirs.empty() || dirs[0] != lib_dir() + "/kernels")) dirs.push_back(lib_dir() + "/kernels");
   for (const std::string &d : dirs) {
     std::ifstream f((d + "/" + name).c_str());
     int v = -1;
@@ -347,6 +346,15 @@ JitKernel jit_load(const std::string &source, const std::string &entry) {
   JitKernel k;
   k.path = jit_compile(source);
   hipError_t e = hipModuleLoad(&k.module, k.path.c_str());
+  if (e != hipSuccess && !std::getenv("FAMSEQ_JIT_SOURCE_ONLY")) {
+    // a cached object that does not load (truncated by a crash, removed under us, written by another compiler): drop it
+    // and build it once more — in a writable cache; a shipped read-only one is left alone and reported
+    (void)hipGetLastError();
+    if (::access(k.path.c_str(), F_OK) != 0 || ::unlink(k.path.c_str()) == 0) {
+      k.path = jit_compile(source);
+      e = hipModuleLoad(&k.module, k.path.c_str());
+    }
+  }
   if (e != hipSuccess) throw std::runtime_error("hipModuleLoad(" + k.path + "): " + hipGetErrorString(e));
   e = hipModuleGetFunction(&k.fn, k.module, entry.c_str());
   if (e != hipSuccess) {

@@ -131,3 +131,38 @@ extern "C" void famseq_call_genotypes(const double *post, int64_t n_rows, int8_t
     geno[r] = pick;
   }
 }
+
+extern "C" int famseq_pedigree_init(famseq_pedigree *p, int32_t n, const int32_t *id, const int32_t *mother_id,
+                                    const int32_t *father_id, const int32_t *gender, const uint8_t *sequenced, double mrate,
+                                    double lc, int32_t *mother_idx, int32_t *father_idx) {
+  if (!p || !id || !mother_id || !father_id || !gender || !mother_idx || !father_idx) return FAMSEQ_E_ARG;
+  if (n < 1) return FAMSEQ_E_ARG;
+  std::memset(p, 0, sizeof(*p));
+  p->n_members = n;
+  p->lc = lc;
+  const double N[3] = {0.9985, 0.001, 0.0005}, K[3] = {0.45, 0.1, 0.45};
+  const double XN[3] = {0.999, 0, 0.001}, XK[3] = {0.5, 0, 0.5};
+  std::memcpy(p->genoProbN, N, sizeof N);
+  std::memcpy(p->genoProbK, K, sizeof K);
+  std::memcpy(p->genoProbXN, XN, sizeof XN);
+  std::memcpy(p->genoProbXK, XK, sizeof XK);
+  famseq_transmission_tables(mrate, p->pcp2, p->pcp2Xf, p->pcp2Xm);
+  p->gender = gender;
+  p->sequenced = sequenced;
+  p->mother = mother_idx;
+  p->father = father_idx;
+  for (int i = 0; i < n; ++i) {
+    // setRelation scans every member without stopping: the last matching id wins (family.cpp:291-350)
+    int im = -1, ifa = -1;
+    for (int j = 0; j < n; ++j) {
+      if (mother_id[i] == id[j]) im = j;
+      if (father_id[i] == id[j]) ifa = j;
+    }
+    if ((im < 0) != (ifa < 0)) return FAMSEQ_E_PED_HALF;
+    mother_idx[i] = im;
+    father_idx[i] = ifa;
+  }
+  for (int i = 0; i < n; ++i)  // checkPed (family.cpp:204-219)
+    if (mother_idx[i] >= 0 && (gender[mother_idx[i]] != 2 || gender[father_idx[i]] != 1)) return FAMSEQ_E_PED_SEX;
+  return 0;
+}

@@ -40,7 +40,7 @@ LdsLayout lds_layout(const Plan &p) {
   return l;
 }
 
-Plan build_plan(const famseq_model &m, const PlanOptions &opt) {
+Plan build_plan(const Model &m, const PlanOptions &opt) {
   const int N = m.n_members;
   if (N < 1 || N > FAMSEQ_MAX_MEMBERS) throw std::runtime_error("n_members out of range");
   std::vector<int> nchild(N, 0);

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "famseq_hip.h"
+#include "model.h"
 
 namespace famseq {
 
@@ -78,7 +79,7 @@ struct Plan {
 };
 
 // Throws std::runtime_error on an invalid model/options.
-Plan build_plan(const famseq_model &m, const PlanOptions &opt);
+Plan build_plan(const Model &m, const PlanOptions &opt);
 
 // LDS carve-up shared by the plan (for occupancy estimates) and the kernel.
 struct LdsLayout {

@@ -36,7 +36,11 @@
 extern "C" {
 #endif
 
-#define FAMSEQ_MAX_MEMBERS 20 /* reference CUDA limit: geno[20], pTmp[60] (family.cu:771-772) */
+/* Limit of the 3^N enumeration engines (and the size of famseq_model's arrays): the reference CUDA file's own,
+ * geno[20], pTmp[60] (family.cu:771-772) — 3^20 = 3.5e9 configurations per site is past any use of an enumeration
+ * anyway.  The sum-product engine (FAMSEQ_ENGINE_ELIM) has no member limit, like the reference's CPU code
+ * (std::vector state, family.cpp:894-941; its -method 2 peeling, :1126-1403, :1501-1845): see famseq_pedigree. */
+#define FAMSEQ_MAX_MEMBERS 20
 
 #define FAMSEQ_ST_OK 0
 #define FAMSEQ_ST_SINGLE_FAIL 1
@@ -75,6 +79,21 @@ typedef struct {
   double lc;         /* m_lc, -LRC                                family.cpp:253-257 */
 } famseq_model;
 
+/* The same for a pedigree of ANY size: the per-member arrays are the caller's ([n_members] each, copied by
+ * famseq_create_pedigree; `sequenced` may be NULL = all sequenced).  Contexts of more than FAMSEQ_MAX_MEMBERS
+ * members serve FAMSEQ_ENGINE_ELIM only — what the reference's -method 2 is recommended for ("family size > 7 and
+ * loop-free", FamSeq_Manual.pdf p.1) — and answer FAMSEQ_E_ARG to a batch call while the engine is the enumeration. */
+typedef struct {
+  int32_t n_members;        /* numInd, >= 1 */
+  const int32_t *mother;    /* [n_members] parent[i][0] or -1    family.cpp:329 */
+  const int32_t *father;    /* [n_members] parent[i][1] or -1    family.cpp:330 */
+  const int32_t *gender;    /* [n_members] 1 = male              family.cpp:1054 */
+  const uint8_t *sequenced; /* [n_members] or NULL               family.cpp:768-771 */
+  double pcp2[27], pcp2Xf[27], pcp2Xm[27];
+  double genoProbN[3], genoProbK[3], genoProbXN[3], genoProbXK[3];
+  double lc;
+} famseq_pedigree;
+
 typedef struct famseq_ctx famseq_ctx;
 
 /* ---- one-time model setup (replaces family ctor + init()) ---------------- */
@@ -89,6 +108,13 @@ int famseq_model_init(famseq_model *m, int32_t n_members, const int32_t *id, con
                       const int32_t *father_id, const int32_t *gender, const uint8_t *sequenced,
                       double mrate, double lc);
 
+/* The same for famseq_pedigree: fills the priors, the tables and lc of *p, and the caller's mother_idx /
+ * father_idx arrays ([n_members] each) with setRelation's indices, and points p->mother / p->father at them;
+ * p->gender and p->sequenced point at the arguments (which must outlive p's use).  Returns 0 or FAMSEQ_E_*. */
+int famseq_pedigree_init(famseq_pedigree *p, int32_t n_members, const int32_t *id, const int32_t *mother_id,
+                         const int32_t *father_id, const int32_t *gender, const uint8_t *sequenced, double mrate,
+                         double lc, int32_t *mother_idx, int32_t *father_idx);
+
 /* ---- context -------------------------------------------------------------- */
 
 int famseq_device_count(void); /* visible HIP devices; 0 when there is none */
@@ -99,6 +125,10 @@ int famseq_device_count(void); /* visible HIP devices; 0 when there is none */
  * device_id < 0 builds a plan-only ctx (for inspection; compute calls return
  * FAMSEQ_E_NODEVICE).  On failure returns NULL with a message in err. */
 famseq_ctx *famseq_create(const famseq_model *model, int device_id, char *err, size_t errlen);
+/* ... from a size-independent model.  Up to FAMSEQ_MAX_MEMBERS members: exactly famseq_create.  Beyond: no
+ * enumeration plan is built, the context starts on FAMSEQ_ENGINE_ELIM (generated and compiled here; fails with a
+ * message when the pedigree's loops need more than three conditioned members). */
+famseq_ctx *famseq_create_pedigree(const famseq_pedigree *pedigree, int device_id, char *err, size_t errlen);
 void famseq_destroy(famseq_ctx *ctx);
 const char *famseq_last_error(famseq_ctx *ctx);
 

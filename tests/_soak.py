@@ -10,19 +10,10 @@ import numpy as np
 
 import famseq_amd as fs
 import oracle
-from famseq_amd.synth import grow_pedigree, random_likelihoods
+from famseq_amd.prebuild_sets import soak_pedigree  # noqa: F401  (one definition: build() pre-compiles these pedigrees)
+from famseq_amd.synth import random_likelihoods
 
 BATCH_SIZES = [1, 63, 64, 255, 256, 257, 511, 513, 1000, 1279, 2048]
-
-
-def soak_pedigree(seed, max_n=10):
-    """-> (rng positioned after the pedigree draw, pedigree, mutation rate): build() pre-compiles
-    the kernels of exactly these pedigrees."""
-    rng = np.random.RandomState(9000 + seed)
-    n = int(rng.randint(3, max_n + 1))
-    ped = grow_pedigree(rng, n, allow_loops=seed % 2 == 0)
-    ped.relations()
-    return rng, ped, [1e-7, 1e-4, 0.0][seed % 3]
 
 
 def run_seed(seed, max_n=10, threads=8):

@@ -116,7 +116,11 @@ def test_the_shipped_pick_table_matches_the_pedigrees_build_prebuilds():
     table = json.load(open(ge.PICKS))
     peds, _ = ge.build_pedigrees()
     keys = {ge.pedigree_key(p) for p in peds}
-    assert keys == set(table), (len(keys), len(table))
+    # every shipped pick belongs to a pedigree whose kernels build() pre-builds (the table may lag behind the build set:
+    # the fixtures' and the wide pedigrees joined it in round 3 and run on the static rules), the benchmark pedigrees are in it
+    assert set(table) <= keys, (len(keys), len(table))
+    import famseq_amd as fs_
+    assert all(ge.pedigree_key(fs_.synthetic_pedigree(n)) in table for n in ("ped5", "ped10", "ped15", "trio", "quad"))
     assert all(v["lane"] in (0, 2) and v["elim"] in (-1, 0, 1) for v in table.values())
 
 
@@ -134,4 +138,5 @@ def test_a_spilling_variant_is_passed_over(tmp_path, monkeypatch):
     notes = sorted(int(open(os.path.join(tmp_path, f)).read()) for f in os.listdir(tmp_path) if f.endswith(".res"))
     assert p["elim_variant"] >= 1 and notes[0] == 0 and notes[-1] > 0
     assert len(notes) == p["elim_variant"] + 1
-    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 1  # the loser keeps its note only
+    # the loser's object stays too: another process sharing the cache may just have been handed its path
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == p["elim_variant"] + 1

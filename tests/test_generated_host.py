@@ -45,6 +45,8 @@ static inline int fs_exp_(double x) { int e; std::frexp(x, &e); return e; }
 #define FS_FREXP_MANT(x) fs_mant_(x)
 #define FS_FREXP_EXP(x) fs_exp_(x)
 #define FS_UMULHI(a, b) ((unsigned)(((unsigned long long)(a) * (unsigned long long)(b)) >> 32))
+static inline int fs_hi32_(double x) { unsigned long long u; __builtin_memcpy(&u, &x, 8); return (int)(u >> 32); }
+#define FS_HI32(x) fs_hi32_(x)
 #define __device__
 #define __forceinline__ inline
 """
@@ -228,11 +230,10 @@ def test_generated_arithmetic_on_random_pedigrees(seed, kind, tmp_path, monkeypa
     every flag combination) against the oracle: the generators' ordering and table logic on shapes
     no fixture has."""
     import oracle
-    from test_gpu_random_pedigrees import grow_pedigree, random_likelihoods
+    from famseq_amd.prebuild_sets import random_pedigree
+    from test_gpu_random_pedigrees import random_likelihoods
 
-    rng = np.random.RandomState(1000 + seed)
-    n = int(rng.randint(3, 10))
-    ped = grow_pedigree(rng, n, allow_loops=seed % 3 == 0)
+    rng, ped = random_pedigree(seed)  # famseq_amd/prebuild_sets.py: build() pre-compiles these pedigrees' kernels
     ped.relations()
     mu = [1e-7, 1e-7, 1e-4, 0.0][seed % 4]
     lk, flags = random_likelihoods(rng, ped, 48)

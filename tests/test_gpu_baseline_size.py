@@ -1,5 +1,5 @@
 """The path at BASELINE.json's own sizes (1 M ped5 sites, 10 M ped10 sites, ped15 at 131,072 sites
-per kernel) on input generated straight into HBM: size-independent properties over the WHOLE
+per kernel and at its full 1 M sites) on input generated straight into HBM: size-independent properties over the WHOLE
 batch — rows are distributions, every status byte 0, bit-reproducible, independent of the site's
 position and of how the batch is cut — plus a sample of sites against the CPU oracle.  Everything
 goes through the C ABI's device entry point (famseq_bn_batch_device)."""
@@ -29,6 +29,7 @@ def _run(ctx, torch, n, lk, flags, post, single, status, first=0, count=None):
     ("ped10", 2, 10_000_000, ("lane", "elim"), 256),           # configs[2] (and [3] per GPU, weak scaling)
     ("ped10", 2, 1_000_000, ("team",), 256),                   # the compiled-in kernel: 0.1 s per M sites
     ("ped15", 4, 131_072, ("team", "lane", "elim"), 2),        # configs[4] shape: 3^15 configurations per site
+    ("ped15", 4, 1_000_000, ("lane", "elim"), 2),              # configs[4] at its full 1 M sites (0.5 s per enumeration launch)
 ])
 def test_properties_at_baseline_size(name, cfg, n_sites, engines, n_oracle):
     import torch

@@ -34,6 +34,45 @@ def test_called_outputs_match_host_formulas(name):
     ctx.close()
 
 
+CALL_ENGINES = [("lane, fused", dict(enum_impl=1)), ("sum-product, fused", dict(engine=fs.ENGINE_ELIM)),
+                ("team + separate stages", dict(enum_impl=0))]
+
+
+@pytest.mark.parametrize("label,opt", CALL_ENGINES, ids=[e[0] for e in CALL_ENGINES])
+@pytest.mark.parametrize("case", list(BY.values()), ids=list(BY))
+def test_called_outputs_match_the_reference_posteriors(case, label, opt):
+    """famseq_bn_call_batch against the COMPILED REFERENCE's posteriors (the fixtures: oracle/gen_golden.py), not against
+    this library's own plain path: GPP / FPP = the drivers' fabs(-10 log10 p) (file.cpp:696-745) of the reference's single /
+    BN posterior, FGT = its arg-max with ties to the lower genotype (family.cpp:636-665), status identical — on every
+    fixture: TestData VCF sites and LK rows, chrX, custom priors, mu = 0, failed sites (status 1 and 2: NaN, -1), shortcut
+    sites (FPP = GPP), for the fused call-path forms of both generated kernels and for the separate stages."""
+    ped = case.pedigree()
+    model = fs.make_model(ped, **case.consts)
+    if "sum-product" in label:
+        probe = fs.Context(model, device=-1)
+        supported = probe.plan()["elim_supported"]
+        probe.close()
+        if not supported:
+            pytest.skip("more loops than the sum-product engine conditions on")
+    ctx = fs.Context(model, **opt)
+    seq = np.nonzero(case.sequenced)[0][::-1].copy()
+    gpp, fpp, fgt, st = ctx.bn_call_batch(seq, lk=case.lk, flags=case.flags)
+    ctx.close()
+    assert np.array_equal(st, case.status)
+    ok, s_ok = (case.status & 3) == 0, (case.status & 3) != 1
+    # posteriors agree with the reference to ~1e-15 relative; a Phred value q = -10 log10 p moves by 4.3 dp/p absolute,
+    # so near p = 1 (q ~ 1e-10) the RELATIVE bar on q is loose and an absolute one of 1e-12 takes over
+    np.testing.assert_allclose(gpp[s_ok], host_phred(case.single[s_ok][:, seq]), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(fpp[ok], host_phred(case.post[ok][:, seq]), rtol=1e-9, atol=1e-11)
+    ref_call = fs.call_genotypes(case.post[ok][:, seq]).reshape(-1, len(seq))
+    p_sorted = np.sort(case.post[ok][:, seq], axis=2)
+    clear = p_sorted[:, :, 2] - p_sorted[:, :, 1] > 1e-12  # (a tie within rounding may fall either way)
+    assert np.array_equal(fgt[ok][clear], ref_call[clear])
+    assert np.all(np.isnan(fpp[~ok])) and np.all(fgt[~ok] == -1) and np.all(np.isnan(gpp[~s_ok]))
+    short = case.status == 0x80
+    assert np.array_equal(fpp[short], gpp[short])
+
+
 def test_packed_pl_input_equals_likelihood_input():
     """PL -> likelihood on the device is the same table the host would use (libm pow), including
     huge PLs (exactly 0), missing samples and unsequenced members (flat {1,1,1})."""

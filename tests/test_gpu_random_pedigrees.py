@@ -7,15 +7,15 @@ import famseq_amd as fs
 import oracle
 from famseq_amd.synth import grow_pedigree, random_likelihoods
 
+from famseq_amd.prebuild_sets import RANDOM_SEEDS, random_pedigree
+
 pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", RANDOM_SEEDS)
 def test_random_pedigree_all_engines(seed):
-    rng = np.random.RandomState(1000 + seed)
-    n = int(rng.randint(3, 10))
-    ped = grow_pedigree(rng, n, allow_loops=seed % 3 == 0)
+    rng, ped = random_pedigree(seed)  # famseq_amd/prebuild_sets.py: build() pre-compiles these pedigrees' kernels
     ped.relations()
     mu = [1e-7, 1e-7, 1e-4, 0.0][seed % 4]
     lk, flags = random_likelihoods(rng, ped, 96)

@@ -7,8 +7,9 @@ import pytest
 
 from _soak import run_seed
 
+from famseq_amd.prebuild_sets import SOAK_SEEDS
+
 pytestmark = pytest.mark.gpu
-SOAK_SEEDS = range(40)
 
 
 @pytest.mark.parametrize("seed", SOAK_SEEDS)
