@@ -78,7 +78,11 @@ struct famseq_ctx {
   int group_digits = -1, last_group_digits = 0;
   int lane_reads_rows = -1;  // does the lane call-path kernel re-read fp64 rows from global memory (unknown until asked)
   int lane_call_variant = -1;  // the variant jit_pick_variant took for it (the answer depends on the variant)
-  int64_t lane_min_sites = 256;  // below this the compiled-in team kernel answers at once (no per-pedigree compile for tiny calls)
+  int64_t lane_min_sites = 256;  // below this the compiled-in team kernel answers at once (no per-pedigree compile for tiny calls) ...
+  // ... unless the generated kernel for that batch is loaded or on disk already (a pre-built pedigree, or one this user has run
+  // before): then nothing has to be waited for and it serves every batch size (team kernel: 0.0237 ms per 256 ten-member
+  // sites, three lanes ... 81 lanes per site: 0.0159).  -1 unknown, 0 would have to be compiled, 1 ready.
+  int grp_ready[kEnumMaxGroupDigits + 1] = {-1, -1, -1, -1, -1};
   // device constants
   uint32_t *d_img = nullptr;
   double *d_tc = nullptr;
@@ -334,10 +338,28 @@ hipError_t launch_elim(famseq_ctx *c, int64_t n_sites, const double *d_lk, const
                           d_post, d_single, d_status, stream);
 }
 
+// Can the generated kernel with 3^d lanes per site run without a compilation (loaded, or its code object on disk)?
+bool generated_ready(famseq_ctx *c, int d) {
+  if ((d == 0 ? c->lane : c->grp[d]).fn) return true;
+  if (d == 0 ? c->lane_failed : c->grp_failed[d]) return false;
+  if (c->grp_ready[d] < 0) {
+    try {
+      const int pick = d == 0 ? jit_read_pick(enumgen_source(c->model, 0, 0)) : -1;
+      // (the variant the loader would take first; a spilling first variant sends it on to others, which may need the compiler:
+      // then this says "not ready" and the tiny batch stays on the compiled-in kernel, which is always right)
+      c->grp_ready[d] = jit_cached(enumgen_source(c->model, pick >= 0 && pick < kEnumVariants ? pick : 0, d)) ? 1 : 0;
+    } catch (const std::exception &) {
+      c->grp_ready[d] = 0;
+    }
+  }
+  return c->grp_ready[d] == 1;
+}
+
 hipError_t launch_engine(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, double *d_post,
                          double *d_single, uint8_t *d_status, hipStream_t stream) {
   if (c->engine == FAMSEQ_ENGINE_ELIM) return launch_elim(c, n_sites, d_lk, d_flags, d_post, d_single, d_status, stream);
-  const bool want_lane = c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites);
+  const bool want_lane = c->enum_impl == 1 || (c->enum_impl < 0 && (n_sites >= c->lane_min_sites ||
+                                                                    generated_ready(c, pick_group_digits(c, n_sites))));
   if (want_lane) {
     int d = pick_group_digits(c, n_sites);
     if (d > 0 && !load_lane(c, d)) d = 0;  // that group size does not build: one lane per site before the compiled-in kernel
@@ -368,7 +390,9 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
     const Model &mdl = c->model;
     std::string src;
     if (elim) {
-      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimVariants, nullptr, elim_first_variant(mdl, true));
+      const bool regs = std::getenv("FAMSEQ_ELIM_CALL_REGS") != nullptr;  // tuning aid: the registers-first family for the call path too
+      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, regs ? kElimVariants : kElimCallVariants, nullptr,
+                             regs ? 4 : elim_first_variant(mdl, true));
     } else {
       // the same block size as the plain lane kernel runs with (variants 0-1 / 2-3: kEnumVariants), so that a batch
       // gives the same bits whether it goes through the fused kernel or through the separate stages
@@ -656,7 +680,8 @@ int tune(famseq_ctx *c) {
       report += "enumeration: one block shape, nothing to choose";
     n = n_elim;
     if (elim_supported(mdl, nullptr))
-      (void)race("sum-product (fence variants)", {0, 1}, [&mdl](int v) { return elim_source(mdl, v); }, "famseq_elim", elim_block_threads(mdl));
+      (void)race("sum-product (likelihoods re-read from LDS: fence-free, fenced; in registers: fence-free, fenced)", {0, 1, 4, 5},
+                 [&mdl](int v) { return elim_source(mdl, v); }, "famseq_elim", elim_block_threads(mdl));
   } catch (const std::exception &e) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -732,6 +757,16 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
       c->elim.path.clear();
       c->elim_variant = -1;
       if (c->engine == FAMSEQ_ENGINE_ELIM) return load_elim(c);
+    }
+    return 0;
+  }
+  else if (k == "prebuild_lane" || k == "prebuild_elim") {  // compile one given variant into the cache (what the tuner will race): no load
+    const bool lane = k == "prebuild_lane";
+    if (value < 0 || value >= (lane ? kEnumVariants : kElimVariants)) return fail(c, FAMSEQ_E_ARG, k + " takes a variant index");
+    try {
+      (void)jit_compile(lane ? enumgen_source(c->model, (int)value, 0) : elim_source(c->model, (int)value));
+    } catch (const std::exception &e) {
+      return fail(c, FAMSEQ_E_HIP, e.what());
     }
     return 0;
   }

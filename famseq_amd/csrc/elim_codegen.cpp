@@ -143,7 +143,10 @@ bool build_graph(const Model &m, Graph &g, std::string *why) {
 
 class Emitter {
  public:
-  Emitter(const Model &m, const Graph &g, int fences, bool scalar_t) : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t) {}
+  // out: where the normalised marginals go — "q" (registers: the shell's compute-first flow) or "row" (the lane's LDS row,
+  // free once the likelihoods sit in registers: the shell's registers-first flow)
+  Emitter(const Model &m, const Graph &g, int fences, bool scalar_t, const char *out = "q")
+      : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t), out_(out) {}
 
   std::string body() {
     if (g_.cut.empty()) {
@@ -218,6 +221,7 @@ class Emitter {
   const Graph &g_;
   const int fences_;  // 0 none, 1 after every family->member message, 2 also after local factors and child sums
   const bool scalar_t_;  // transmission entries from tcx[] (uniform pointer: scalar loads) instead of the lane's LDS table
+  const std::string out_;
   std::ostringstream o_;
   std::map<std::string, bool> done_;
   int uid_ = 0;
@@ -354,10 +358,14 @@ class Emitter {
 
   // row p of the output: `from`_g / sum, with the reference's failure rule (family.cpp:943-954)
   void normalise(int p, const std::string &from) {
+    // one division per row and three products (this engine is not bit-ordered anyway); a row sum in the subnormal range,
+    // whose reciprocal overflows, keeps the three divisions behind a real branch (as the enumeration kernel does)
+    auto o3 = [&](int g) { return out_ + "[" + num(3 * p + g) + "]"; };
     o_ << "      { const double s = (" << from << "_0 + " << from << "_1) + " << from << "_2; if (s <= 0) bn_fail = true;\n"
-       << "        const double r = 1.0 / s;  // one division per row; this engine is not bit-ordered anyway\n"
-       << "        q[" << 3 * p << "] = " << from << "_0 * r; q[" << 3 * p + 1 << "] = " << from << "_1 * r; q[" << 3 * p + 2
-       << "] = " << from << "_2 * r; }\n";
+       << "        if (s < 1e-290) { asm volatile(\"\" ::: \"memory\"); " << o3(0) << " = " << from << "_0 / s; " << o3(1) << " = " << from << "_1 / s; "
+       << o3(2) << " = " << from << "_2 / s; }\n"
+       << "        else { const double r = 1.0 / s; " << o3(0) << " = " << from << "_0 * r; " << o3(1) << " = " << from << "_1 * r; " << o3(2) << " = "
+       << from << "_2 * r; } }\n";
   }
 };
 
@@ -394,7 +402,10 @@ int elim_block_threads(const Model &m, bool call_mode) {
   return 64;
 }
 
-int elim_first_variant(const Model &m, bool call_mode) { return !call_mode && m.n_members == 11 ? 1 : 0; }
+// Registers-first from five members on (see kElimVariants); within a family the fence-free variant, with which
+// jit_pick_variant starts unless it spills.  (Round 2's "the fenced variant at eleven members" was fitted to the r = 0
+// family's survey and is not carried over; a pedigree that has been MEASURED starts from its note either way.)
+int elim_first_variant(const Model &m, bool call_mode) { return !call_mode && m.n_members >= 5 ? 4 : 0; }
 
 // Text every generated kernel carries for the fused call path (SURVEY.md 8(f) rows N2 + N4): packed
 // integer PLs staged straight into the LDS rows (the reference's lk = pow(10, -|PL| / 10), file.cpp:588-590,
@@ -775,12 +786,18 @@ std::string elim_source(const Model &m, int variant, bool call_mode) {
   // variant 0: no compiler fences (most overlap between the message blocks; fits small pedigrees),
   //         1: a fence after every family->member message, 2: also after local factors and child
   //         summaries, 3: also between the members of the single posterior
-  return kernel_shell(m, "famseq_elim",
-                      "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families" +
-                          (g.cut.empty() ? "" : ", conditioned on " + std::to_string(g.cut.size()) + " member(s)") +
-                          ", variant " + std::to_string(variant) + (call_mode ? ", call path" : ""),
-                      Emitter(m, g, variant < 2 ? variant : 2, /*scalar_t=*/variant >= 1).body(), bt, min_waves,
-                      /*regs_l=*/false, variant >= 3, /*chrx_loop=*/variant >= 1, 0, call_mode);
+  // Where the likelihoods live during the message passing: re-read from the lane's LDS row at each use (short live ranges:
+  // what the narrow pedigrees' kernels want, they run at two or more waves per SIMD), or — registers-first — read once into
+  // registers, the row then being the output stage (no q[] array, a tenth of the LDS reads, all of them issued together).
+  bool regs_l = variant >= 4 && (!call_mode || std::getenv("FAMSEQ_ELIM_CALL_REGS"));
+  if (const char *e = std::getenv("FAMSEQ_ELIM_REGS")) regs_l = std::atoi(e) != 0 && !call_mode;  // tuning aid
+  variant &= 3;  // the fence level
+  const std::string what = "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families" +
+                           (g.cut.empty() ? "" : ", conditioned on " + std::to_string(g.cut.size()) + " member(s)") + ", variant " +
+                           std::to_string(variant + (regs_l ? 4 : 0)) + (regs_l ? " (likelihoods in registers)" : "") + (call_mode ? ", call path" : "");
+  return kernel_shell(m, "famseq_elim", what,
+                      Emitter(m, g, variant < 2 ? variant : 2, /*scalar_t=*/variant >= 1, regs_l ? "row" : "q").body(), bt, min_waves,
+                      regs_l, variant >= 3, /*chrx_loop=*/variant >= 1, 0, call_mode);
 }
 
 }  // namespace famseq

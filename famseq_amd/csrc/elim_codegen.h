@@ -15,9 +15,16 @@ bool elim_supported(const Model &m, std::string *why);
 int elim_conditioned_members(const Model &m);
 // HIP source of `extern "C" __global__ famseq_elim(lk, flags, post, single, status, n_sites, tc, lc)`
 // specialised for the model's topology, sexes and sequenced set.  Throws if unsupported.
-// variant 0..kElimVariants-1: decreasing instruction-level parallelism / register pressure
-// (jit_pick_variant takes the first that does not spill)
-constexpr int kElimVariants = 4;
+// variant = 4 * r + f.  f = 0..3: decreasing instruction-level parallelism / register pressure (0 no compiler fences,
+// 1 a fence per family->member message and the transmission tables through scalar loads, 2 fences after every block,
+// 3 also between the members of the single posterior).  r: where the likelihoods live during the message passing —
+// 0 re-read from the lane's LDS row at each use (the marginals wait in registers until the row is free), 1 read once
+// into registers, the row being the output stage from then on (a tenth of the LDS reads, issued together; round 3:
+// equal for trios and quads, +2...17 % from five members on with one exception in ten pedigrees, x1.4-2 beyond twenty
+// members: profiles/r03a/exp_elim_registers_first*.txt).  jit_pick_variant takes the first that does not spill, from
+// elim_first_variant on.  The call-path form has the r = 0 family only.
+constexpr int kElimVariants = 8;
+constexpr int kElimCallVariants = 4;
 // call_mode: the fused call path's form (packed PLs or fp64 rows in; GPP / FPP / FGT / status out)
 std::string elim_source(const Model &m, int variant, bool call_mode = false);
 int elim_block_threads(const Model &m, bool call_mode = false);

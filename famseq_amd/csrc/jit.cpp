@@ -276,6 +276,17 @@ std::string jit_compile(const std::string &source, int *scratch_bytes, bool note
   return obj;
 }
 
+bool jit_cached(const std::string &source) {
+  char name[40];
+  std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(source + kCompilerTag));
+  if (!std::getenv("FAMSEQ_KERNEL_CACHE") && exists(lib_dir() + "/kernels/" + name + ".hsaco")) return true;
+  try {
+    return exists(cache_dir() + "/" + name + ".hsaco");
+  } catch (const std::exception &) {
+    return false;
+  }
+}
+
 // A couple of spilled registers cost less than the next variant's lost overlap (measured: 12 B of
 // scratch on the fence-free 5-member sum-product kernel, still 7 % faster than the fenced one).
 constexpr int kSpillTolerance = 16;  // bytes per lane

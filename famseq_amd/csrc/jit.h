@@ -31,6 +31,9 @@ JitKernel jit_load(const std::string &source, const std::string &entry);
 // note_suffices: when the object is not there but its resource note is (a variant that lost an earlier
 // jit_pick_variant), return "" with *scratch_bytes set instead of compiling again.
 std::string jit_compile(const std::string &source, int *scratch_bytes = nullptr, bool note_suffices = false);
+// Is the code object of `source` on disk already (shipped next to the library or in the cache)?  Loading it then takes
+// no compilation: what decides whether a tiny batch may be served by a generated kernel.
+bool jit_cached(const std::string &source);
 // The generators can trade instruction-level parallelism against register pressure
 // (`variant` 0 = most parallel).  Compiles variants in order and returns the source of the
 // first one that does not spill (more than 16 bytes per lane), or of the one that spills least.  *picked = its index.

@@ -146,11 +146,13 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *                   otherwise (tiny calls never wait for a compile)
  *   "tune"          1 = time the candidates of this pedigree's generated kernels on this device (where a static rule
  *                   picks a variant: the enumeration kernel's 7- or 6-member unrolled block, the sum-product kernel's
- *                   fence variant) on synthetic rows, a few milliseconds each, and keep the winners' indices as notes
+ *                   fence variant and where it keeps the likelihoods) on synthetic rows, a few milliseconds each, and keep the winners' indices as notes
  *                   in the kernel cache — every later context for the pedigree starts from them; compiles every
  *                   candidate (seconds each), needs a device; famseq_plan_json "tune" reports what was measured
  *   "pick_lane", "pick_elim"  a variant index measured elsewhere, kept as the note "tune" would leave (how build() ships
  *                   its table of measured picks); works on a plan-only context
+ *   "prebuild_lane", "prebuild_elim"  compile that variant of the pedigree's kernel into the cache without loading it
+ *                   (a plan-only context will do): how a build host prepares every candidate "tune" races
  *   "group_digits"  the generated kernel's lanes per site, 3^d: d = 0 one lane per site (large batches),
  *                   d = 1..4 lanes-per-site mode for batches too small to give every lane of the chip a
  *                   site (each lane of a group enumerates one combination of the d outermost looped

@@ -141,6 +141,26 @@ int main() {
     CHECK(famseq_create(&m, -1, err, sizeof err) == nullptr && std::strlen(err) > 0);
     CHECK(famseq_create(nullptr, -1, err, sizeof err) == nullptr);
   }
+  {  // the size-independent model: a 40-member chain through famseq_pedigree (the generators run, nothing compiles);
+     // creation fails for want of a compiler — cleanly, with the reason — and the argument checks hold
+    const Ped w = chain(40);
+    const int n = (int)w.id.size();
+    std::vector<int32_t> mo(n), fa(n);
+    famseq_pedigree p;
+    CHECK(famseq_pedigree_init(&p, n, w.id.data(), w.mo.data(), w.fa.data(), w.sex.data(), nullptr, 1e-7, 1.0, mo.data(), fa.data()) == 0);
+    CHECK(p.n_members == n && p.mother == mo.data() && p.sequenced == nullptr);
+    famseq::Model model(p);
+    size_t bytes = 0;
+    for (int v = 0; v < famseq::kElimVariants; ++v) bytes += famseq::elim_source(model, v).size();
+    CHECK(bytes > 100000);
+    char err[256] = "";
+    CHECK(famseq_create_pedigree(&p, -1, err, sizeof err) == nullptr && std::strstr(err, "sum-product engine only") != nullptr);
+    CHECK(famseq_create_pedigree(nullptr, -1, err, sizeof err) == nullptr);
+    CHECK(famseq_pedigree_init(&p, n, w.id.data(), w.mo.data(), w.fa.data(), w.sex.data(), nullptr, 1e-7, 1.0, nullptr, fa.data()) == FAMSEQ_E_ARG);
+    p.mother = nullptr;  // a struct without its arrays is refused, not dereferenced
+    CHECK(famseq_create_pedigree(&p, -1, err, sizeof err) == nullptr);
+    std::printf("chain40  N=40 through famseq_pedigree: %zu bytes of generated source\n", bytes);
+  }
   double t0[27], t1[27], t2[27];
   for (double mu : {0.0, 1e-7, 1e-3, 0.5}) famseq_transmission_tables(mu, t0, t1, t2);
   CHECK(famseq_last_error(nullptr) != nullptr);

@@ -52,5 +52,33 @@ int main(void) {
   printf("gpu: child posterior %.6g %.6g %.6g, calls %d %d %d\n", post[0][2][0], post[0][2][1], post[0][2][2], gt[0], gt[1], gt[2]);
   if (gt[0] != 0 || gt[1] != 1) return 22;
   famseq_destroy(c);
+
+  /* the size-independent model: a 22-member pedigree (two founders, twenty children) through famseq_pedigree —
+   * beyond famseq_model's arrays, served by the sum-product engine only */
+  {
+    enum { NW = 22 };
+    int32_t wid[NW], wmid[NW], wfid[NW], wsex[NW], wmo[NW], wfa[NW];
+    for (int i = 0; i < NW; i++) wid[i] = i + 1, wmid[i] = i < 2 ? 0 : 2, wfid[i] = i < 2 ? 0 : 1, wsex[i] = i == 0 ? 1 : (i == 1 ? 2 : 1 + i % 2);
+    famseq_pedigree wp;
+    if (famseq_pedigree_init(&wp, NW, wid, wmid, wfid, wsex, NULL, 1e-7, 1.0, wmo, wfa) != 0) return 30;
+    if (wp.mother[5] != 1 || wp.father[5] != 0 || wp.mother[0] != -1) return 31;
+    famseq_ctx *w = famseq_create_pedigree(&wp, 0, err, sizeof err);
+    if (!w) {
+      fprintf(stderr, "%s\n", err);
+      return 32;
+    }
+    if (famseq_set_option(w, "engine", FAMSEQ_ENGINE_ENUM) != FAMSEQ_E_ARG) return 33; /* 3^22 is no enumeration's business */
+    double wlk[2][NW][3], wpost[2][NW][3], wsingle[2][NW][3];
+    uint8_t wst[2] = {9, 9};
+    for (int s2 = 0; s2 < 2; s2++)
+      for (int i = 0; i < NW; i++) wlk[s2][i][0] = 1.0, wlk[s2][i][1] = 1e-2 * (1 + (i + s2) % 3), wlk[s2][i][2] = 1e-5;
+    if (famseq_bn_batch(w, 2, &wlk[0][0][0], NULL, &wpost[0][0][0], &wsingle[0][0][0], wst) != 0) return 34;
+    for (int s2 = 0; s2 < 2; s2++)
+      for (int i = 0; i < NW; i++)
+        if (!(fabs(wpost[s2][i][0] + wpost[s2][i][1] + wpost[s2][i][2] - 1.0) < 1e-12)) return 35;
+    if (wst[0] != FAMSEQ_ST_OK || wst[1] != FAMSEQ_ST_OK) return 36;
+    printf("gpu: 22-member pedigree through famseq_create_pedigree, child 3 posterior %.6g %.6g %.6g\n", wpost[0][2][0], wpost[0][2][1], wpost[0][2][2]);
+    famseq_destroy(w);
+  }
   return 0;
 }

@@ -24,4 +24,4 @@ def test_c_program_links_and_fails_loudly_without_gpu(tmp_path):
 def test_c_program_computes_on_gpu(tmp_path):
     p = subprocess.run([build(tmp_path)], capture_output=True, text=True)
     assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
-    assert "gpu: child posterior" in p.stdout
+    assert "gpu: child posterior" in p.stdout and "22-member pedigree through famseq_create_pedigree" in p.stdout

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two gloo ranks shard the seeded site stream, each computes its own
+"""N > 1 path on CPU: two and eight gloo ranks shard the seeded site stream, each computes its own
 range (the oracle stands in for the GPU here — this test is about the sharding/gather
 logic), and the gathered result equals the single-process result."""
 import os
@@ -8,6 +8,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from famseq_amd.shard import site_range
 
@@ -49,7 +50,10 @@ def test_site_ranges_tile():
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
 
 
-def test_two_rank_gloo_shard_and_gather(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_ranks_shard_and_gather(world, tmp_path):
+    """world = 8 is the driver's SCALE shape (one rank per GPU of the node): ragged ranges (301 sites over 8 ranks: 37 or 38
+    each), the gather's padding and order, the max-over-ranks reduction bench.py's timing uses."""
     import oracle
     from famseq_amd import pedigree, synth
 
@@ -60,7 +64,7 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     script.write_text(WORKER)
     out = tmp_path / "full.npy"
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), str(out)],
                           env=env, timeout=300)
     ped = pedigree.synthetic_pedigree("ped5")

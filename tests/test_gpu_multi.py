@@ -230,8 +230,8 @@ def test_tune_times_the_variants_and_later_contexts_start_from_the_pick(tmp_path
     before = ctx.bn_batch(lk, flags)
     ctx.set_option("tune", 1)
     plan = ctx.plan()
-    assert "enumeration (7- / 6-member block): v0" in plan["tune"] and "sum-product (fence variants): v0" in plan["tune"], plan["tune"]
-    assert plan["enum_lane_variant"] in (0, 2)
+    assert "enumeration (7- / 6-member block): v0" in plan["tune"] and "sum-product (likelihoods re-read from LDS" in plan["tune"], plan["tune"]
+    assert plan["enum_lane_variant"] in (0, 2) and ("loaded: enumeration v%d" % plan["enum_lane_variant"]) in plan["tune"]
     after = ctx.bn_batch(lk, flags)
     np.testing.assert_allclose(after[0], before[0], rtol=1e-12, atol=0)
     assert np.array_equal(after[1].view(np.uint64), before[1].view(np.uint64)) and np.array_equal(after[2], before[2])
@@ -241,6 +241,7 @@ def test_tune_times_the_variants_and_later_contexts_start_from_the_pick(tmp_path
     picks = sorted(f.name for f in tmp_path.iterdir() if f.name.endswith(".pick"))
     assert len(picks) == 2
     lane_pick, elim_pick = plan["enum_lane_variant"], ctx.plan()["elim_variant"]
+    assert elim_pick in (0, 1, 4, 5) and ("-> v%d" % elim_pick) in plan["tune"]  # the report names what gets loaded
     ctx.close()
     # a later context: same picks, nothing timed
     ctx = fs.Context(model, enum_impl=1)

@@ -249,81 +249,6 @@ __global__ __launch_bounds__(BT, 2) void shell2(const double *__restrict__ in, d
 }
 
 
-// Round-2 experiment: the same traffic with LDS-DMA staging.  One wave per workgroup
-// (no workgroup barrier anywhere), the chunk's 64 rows land in LDS as an unpadded image through
-// global_load_lds_dwordx4 (no VGPRs, no ds_write), double-buffered: the DMA of chunk k + 1 is issued before
-// chunk k is computed and stays in flight through its compute and output phases.  The consumed input buffer
-// is the output stage.  vmcnt is counted: loads, DMA and stores retire in order, so the chunk-k image is
-// complete once all but the younger operations (the two output phases of chunk k - 1 and the DMA of k + 1)
-// have retired.
-template <int W3, int WORK, bool NT>
-__global__ __launch_bounds__(64) void shell_dma(const double *__restrict__ in, double *__restrict__ o1,
-                                                double *__restrict__ o2, long n_sites) {
-  constexpr int CH = 64 * W3;                   // doubles per chunk
-  constexpr int PIECES = (CH + 127) / 128;      // 1 KiB wave-instructions per chunk (the last one half-full when W3 is odd)
-  __shared__ double buf[2][PIECES * 128];
-  typedef __attribute__((address_space(1))) const void gvoid;
-  typedef __attribute__((address_space(3))) void lvoid;
-  const int t = threadIdx.x;
-  const long groups = n_sites / 64;
-  const long per = (groups + gridDim.x - 1) / gridDim.x;
-  const long c_lo = (long)blockIdx.x * per, c_hi = c_lo + per < groups ? c_lo + per : groups;
-  auto dma = [&](int b, long ch) {
-    const double *src = in + ch * CH;
-#pragma unroll
-    for (int p = 0; p < PIECES; ++p)
-      if (p * 128 + 2 * t < CH) __builtin_amdgcn_global_load_lds((gvoid *)(src + p * 128 + 2 * t), (lvoid *)(buf[b] + p * 128), 16, 0, 0);
-  };
-  if (c_lo < c_hi) dma(0, c_lo);
-  for (long ch = c_lo; ch < c_hi; ++ch) {
-    const int b = (int)(ch - c_lo) & 1;
-    WAVE_SYNC();  // the other buffer's last readers (output staging of the previous chunk) are done
-    const bool more = ch + 1 < c_hi;
-    if (more) dma(b ^ 1, ch + 1);
-    // chunk ch's image: everything older than the 2 * PIECES stores of the previous chunk and this DMA has retired
-    if (more && ch > c_lo) __builtin_amdgcn_s_waitcnt(((3 * PIECES) & 15) | (((3 * PIECES) >> 4) << 14) | 0x0F70);
-    else if (more) __builtin_amdgcn_s_waitcnt((PIECES & 15) | ((PIECES >> 4) << 14) | 0x0F70);
-    else __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" ::: "memory");
-    double *row = buf[b] + t * W3;
-    double l[W3];
-#pragma unroll
-    for (int k = 0; k < W3; ++k) l[k] = row[k];
-    double acc = 0;
-#pragma unroll
-    for (int k = 0; k < W3; ++k) acc += l[k];
-    for (int w = 0; w < WORK; ++w) {
-#pragma unroll
-      for (int k = 0; k < W3; ++k) l[k] = l[k] * 0.999 + acc * 1e-9;
-    }
-    auto stage_out = [&](double *__restrict__ dst) {
-      WAVE_SYNC();
-      v2d *d2 = (v2d *)(dst + ch * CH);
-#pragma unroll
-      for (int p = 0; p < PIECES; ++p)
-        if (p * 128 + 2 * t < CH) {
-          const v2d v = *(const v2d *)(buf[b] + p * 128 + 2 * t);
-          if (NT) __builtin_nontemporal_store(v, d2 + p * 64 + t); else d2[p * 64 + t] = v;
-        }
-      WAVE_SYNC();
-    };
-#pragma unroll
-    for (int k = 0; k < W3; ++k) row[k] = l[k] / acc;
-    stage_out(o2);
-#pragma unroll
-    for (int k = 0; k < W3; ++k) row[k] = l[k] * acc;
-    stage_out(o1);
-  }
-}
-
-__global__ void fill_idx(double *p, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    p[i] = 1.0 + (double)(i % 1000003) * 1e-6;
-}
-__global__ void diff_count(const double *a, const double *b, size_t n, unsigned long long *bad) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    if (a[i] != b[i]) atomicAdd(bad, 1ull);
-}
 
 template <class F>
 static void time_it(const char *name, size_t bytes, F launch) {
@@ -389,39 +314,6 @@ static void run(long n_sites) {
   S2(true, true, 8, false);
   S2(true, false, 32, false);
   S2(true, true, 32, false);
-  {
-    int nd = 0;
-    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nd, shell_dma<W3, 0, true>, 64, 0));
-    printf("shell_dma: %d one-wave workgroups per CU\n", nd);
-    for (int per_cu : {nd, nd > 4 ? 4 : nd, 8 < nd ? 8 : nd}) {
-      char nm[64];
-#define SD(WK, NT) \
-      snprintf(nm, sizeof nm, "shell_dma work=" #WK " nt=" #NT " %d/CU", per_cu); \
-      time_it(nm, bytes, [&] { shell_dma<W3, WK, NT><<<256 * per_cu, 64>>>(in, o1, o2, n_sites); })
-      SD(0, true);
-      SD(0, false);
-      SD(8, true);
-      SD(32, true);
-    }
-  }
-  {  // the DMA shell moves the same values to the same places as the register-staged one
-    double *r1, *r2;
-    unsigned long long *bad, h = 0;
-    CHECK(hipMalloc(&r1, n * 8));
-    CHECK(hipMalloc(&r2, n * 8));
-    CHECK(hipMalloc(&bad, 8));
-    CHECK(hipMemset(bad, 0, 8));
-    fill_idx<<<2048, 256>>>(in, n);
-    shell2<W3, BT, true, false, 0, false><<<grid, BT>>>(in, r1, r2, n_sites);
-    shell_dma<W3, 0, true><<<256 * 5, 64>>>(in, o1, o2, n_sites);
-    diff_count<<<2048, 256>>>(r1, o1, n, bad);
-    diff_count<<<2048, 256>>>(r2, o2, n, bad);
-    CHECK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost));
-    printf("shell_dma vs shell2 outputs: %llu differing elements of %zu\n", h, 2 * n);
-    CHECK(hipFree(r1));
-    CHECK(hipFree(r2));
-    CHECK(hipFree(bad));
-  }
   time_it("lds8c 64/wg", bytes, [&] { lds_shell<W3, 64, false, 1><<<grid * 4, 64>>>(in, o1, o2, n_sites); });
   time_it("lds16i 64/wg", bytes, [&] { lds_shell<W3, 64, true, 2><<<grid * 4, 64>>>(in, o1, o2, n_sites); });
   CHECK(hipFree(in));

@@ -9,12 +9,13 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["FAMSEQ_KERNEL_CACHE"] = tempfile.mkdtemp(prefix="famseq_picks_")
+if os.environ.get("FAMSEQ_PICKS_SCRATCH_CACHE"):  # (default: the in-tree cache, where tools/prebuild_candidates.py put the candidates)
+    os.environ["FAMSEQ_KERNEL_CACHE"] = tempfile.mkdtemp(prefix="famseq_picks_")
 import famseq_amd as fs  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 
 out = sys.argv[1]
-peds, _ = ge.build_pedigrees()
+peds = ge.tuned_pedigrees()
 table, t0 = {}, time.time()
 for k, ped in enumerate(peds):
     key = ge.pedigree_key(ped)
