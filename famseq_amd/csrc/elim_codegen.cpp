@@ -405,7 +405,14 @@ int elim_block_threads(const Model &m, bool call_mode) {
 // Registers-first from five members on (see kElimVariants); within a family the fence-free variant, with which
 // jit_pick_variant starts unless it spills.  (Round 2's "the fenced variant at eleven members" was fitted to the r = 0
 // family's survey and is not carried over; a pedigree that has been MEASURED starts from its note either way.)
-int elim_first_variant(const Model &m, bool call_mode) { return !call_mode && m.n_members >= 5 ? 4 : 0; }
+// From forty members on the form without LDS staging (variants 8..): at 48 members the staged form's 74 KB of LDS rows per wave
+// leave two waves per CU and it runs at 0.28 of HBM peak (the unstaged one, four waves per CU: 0.35); from about a hundred the
+// rows no longer fit the CU's 160 KB at all (profiles/r03a/exp_elim_unstaged.txt: 24 members 0.52 staged / 0.37 unstaged, 32:
+// 0.52 / 0.38, 48: 0.28 / 0.35, 64: - / 0.24, 96: - / 0.15 — past sixty members the registers spill and scratch traffic sets the pace).
+int elim_first_variant(const Model &m, bool call_mode) {
+  if (call_mode) return 0;
+  return m.n_members >= 40 ? 8 : (m.n_members >= 5 ? 4 : 0);
+}
 
 // Text every generated kernel carries for the fused call path (SURVEY.md 8(f) rows N2 + N4): packed
 // integer PLs staged straight into the LDS rows (the reference's lk = pow(10, -|PL| / 10), file.cpp:588-590,
@@ -774,10 +781,78 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
   return s.str();
 }
 
+namespace {
+
+// The shell without LDS staging (variants 8..11: the widest pedigrees): a lane reads its site's row straight from global
+// memory into registers and stores its single posterior and marginal rows straight back — 8 bytes per lane and
+// instruction, a cache line per lane.  What the staged shell buys with its LDS rows (coalesced 16-byte accesses) costs it
+// the CU's LDS: 3N doubles per lane leave two waves per CU at 48 members and nothing beyond about a hundred; this form
+// needs 3.4 KB of LDS (the factor tables) whatever N is, runs four waves per CU, and has no barrier after the first.
+std::string direct_shell(const Model &m, const std::string &comment, const std::string &body, int bt, bool fence_single, bool chrx_loop) {
+  const int N = m.n_members, W3 = 3 * N;
+  std::ostringstream s;
+  s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
+    << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n#pragma clang fp contract(off)\n"
+    << "#define W3 " << W3 << "\n#define BT " << bt << "\n"
+    << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
+    << "extern \"C\" __global__ __launch_bounds__(BT, 1) void famseq_elim(const double *__restrict__ lk_g,\n"
+    << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
+    << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
+    << "  __shared__ double s_tc[432];\n"
+    << "  const int tid = threadIdx.x;\n"
+    << "  for (int i = tid; i < 432; i += BT) s_tc[i] = tc_g[i];\n"
+    << "  LDS_BARRIER();\n"
+    << "  const long chunks = (n_sites + BT - 1) / BT;\n"
+    << "  const long q_wg = chunks / gridDim.x, r_wg = chunks - q_wg * gridDim.x;\n"
+    << "  const long c_lo = (long)blockIdx.x * q_wg + (blockIdx.x < r_wg ? blockIdx.x : r_wg), c_hi = c_lo + q_wg + (blockIdx.x < r_wg ? 1 : 0);\n"
+    << "  const double kNaN = __builtin_nan(\"\");\n"
+    << "  for (long ch = c_lo; ch < c_hi; ++ch) {\n"
+    // a lane beyond the batch's end works on the last site: the same values to the same addresses as that site's own lane
+    << "    const long site = ch * BT + tid < n_sites ? ch * BT + tid : n_sites - 1;\n"
+    << "    const double *lg = lk_g + site * W3;\n"
+    << "    double *pg = post_g + site * W3;\n"
+    << "    double *row = single_g ? single_g + site * W3 : pg;  // where the single posterior goes\n"
+    << "    const int fl = flags_g ? (flags_g[site] & 3) : 0;\n"
+    << "    const double *tcf = s_tc + fl * 108;\n"
+    << "    bool single_fail = false, full = false, bn_fail = false;\n";
+  for (int p = 0; p < N; ++p)
+    for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = lg[" << 3 * p + gt << "];\n";
+  s << single_posterior_statements(m, true, true, fence_single)
+    << "    if (single_fail) {\n#pragma unroll 1\n      for (int k = 0; k < W3; ++k) row[k] = kNaN;\n    }\n"
+    // a site that does not take the full computation: its posterior IS the single posterior (family.cpp:793-878) or NaN
+    << "    if (single_g && !(full && !single_fail)) {\n#pragma unroll 1\n      for (int k = 0; k < W3; ++k) pg[k] = row[k];\n    }\n";
+  if (chrx_loop)
+    s << "    {\n      const int chrx_ = fl >> 1;\n"
+      << "#pragma unroll 1\n"
+      << "      for (int x_ = 0; x_ < 2; ++x_) {\n"
+      << "        const bool mine_ = full && !single_fail && chrx_ == x_;\n"
+      << "        if (__builtin_amdgcn_ballot_w64(mine_) == 0) continue;\n"
+      << "        const double *tcx = tc_g + x_ * 216;\n"
+      << "        if (mine_) {\n";
+  else
+    s << "    if (full && !single_fail) {\n";
+  s << body
+    << "      if (bn_fail) {\n#pragma unroll 1\n        for (int k = 0; k < W3; ++k) pg[k] = kNaN;\n      }\n"
+    << (chrx_loop ? "        }\n      }\n    }\n" : "    }\n")
+    << "    if (status_g) status_g[site] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
+    << "  }\n}\n";
+  return s.str();
+}
+
+}  // namespace
+
 std::string elim_source(const Model &m, int variant, bool call_mode) {
   Graph g;
   std::string why;
   if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);
+  if (variant >= 8 && !call_mode) {  // no LDS staging: see direct_shell
+    const int f = variant & 3;
+    return direct_shell(m,
+                        "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families" +
+                            (g.cut.empty() ? "" : ", conditioned on " + std::to_string(g.cut.size()) + " member(s)") + ", variant " +
+                            std::to_string(variant) + " (rows straight from and to global memory)",
+                        Emitter(m, g, f < 2 ? f : 2, /*scalar_t=*/f >= 1, "pg").body(), elim_block_threads(m, false), f >= 3, /*chrx_loop=*/f >= 1);
+  }
   const int bt = elim_block_threads(m, call_mode);
   int min_waves = call_mode && m.n_members <= 10 ? 2 : 1;
   if (const char *e = std::getenv("FAMSEQ_ELIM_MINWAVES")) min_waves = std::atoi(e);  // tuning aid

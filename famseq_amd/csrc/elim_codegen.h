@@ -23,7 +23,7 @@ int elim_conditioned_members(const Model &m);
 // equal for trios and quads, +2...17 % from five members on with one exception in ten pedigrees, x1.4-2 beyond twenty
 // members: profiles/r03a/exp_elim_registers_first*.txt).  jit_pick_variant takes the first that does not spill, from
 // elim_first_variant on.  The call-path form has the r = 0 family only.
-constexpr int kElimVariants = 8;
+constexpr int kElimVariants = 12;  // 8..11 (r = 2): no LDS staging at all, rows straight from and to global memory (the widest pedigrees)
 constexpr int kElimCallVariants = 4;
 // call_mode: the fused call path's form (packed PLs or fp64 rows in; GPP / FPP / FGT / status out)
 std::string elim_source(const Model &m, int variant, bool call_mode = false);

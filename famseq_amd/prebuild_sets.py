@@ -9,6 +9,7 @@ SOAK_SEEDS = range(40)          # tests/test_gpu_soak.py
 RANDOM_SEEDS = range(10)        # tests/test_gpu_random_pedigrees.py, tests/test_generated_host.py
 WIDE_SIZES = (24, 32, 48)       # tests/golden/wide_peds.npz (oracle/gen_golden_wide.py)
 WIDE_RANDOM_SEEDS = range(6)    # tests/test_gpu_wide.py
+WIDE_EXTRA_SIZES = (128,)       # beyond what LDS rows could stage: tests/test_wide.py, tests/test_gpu_wide.py (against the numpy oracle)
 
 
 def soak_pedigree(seed, max_n=10):

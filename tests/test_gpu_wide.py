@@ -65,6 +65,34 @@ def test_random_wide_pedigrees_against_the_pinned_oracle(seed):
     assert np.all(np.isnan(post[(status & 3) != 0]))
 
 
+def test_a_pedigree_wider_than_lds_rows_could_stage():
+    """128 members through the kernel form without LDS staging, ragged batch, against the numpy oracle."""
+    import oracle.sum_product as sp
+    from famseq_amd.prebuild_sets import wide_pedigree
+
+    ped = wide_pedigree(128)
+    rng = np.random.RandomState(128)
+    s = 1000
+    pl = rng.randint(0, 120, size=(s, ped.n, 3)).astype(float)
+    pl[np.arange(s)[:, None], np.arange(ped.n)[None, :], rng.randint(0, 3, size=(s, ped.n))] = 0
+    lk = 10.0 ** (-pl / 10.0)
+    lk[:, ped.sequenced == 0, :] = 1.0
+    lk[7] = 1.0
+    lk[7, ped.sequenced == 1] = [1.0, 1e-17, 1e-20]  # a shortcut site
+    lk[9, int(np.nonzero(ped.sequenced)[0][3])] = 0.0  # a site whose single posterior fails
+    flags = rng.randint(0, 4, s).astype(np.uint8)
+    want = sp.pedigree_posterior(ped, lk, flags)
+    ctx = fs.Context(fs.make_model(ped), device=0)
+    assert ctx.plan()["elim_variant"] >= 8
+    post, single, status = ctx.bn_batch(lk, flags)
+    ctx.close()
+    assert np.array_equal(status, want[2]) and status[7] == 0x80 and status[9] == 1
+    ok, s_ok = (status & 3) == 0, (status & 3) != 1
+    assert np.array_equal(single[s_ok], want[1][s_ok])
+    np.testing.assert_allclose(post[ok], want[0][ok], rtol=1e-9, atol=1e-300)
+    assert np.all(np.isnan(post[~ok])) and np.all(np.isnan(single[~s_ok]))
+
+
 def test_call_path_of_a_wide_pedigree():
     """famseq_bn_call_batch (packed PLs in, GPP / FPP / FGT out) on the 32-member pedigree: separate unpack /
     posterior / Phred stages (no fused form beyond 20 members), against the drivers' formulas (file.cpp:696-745,

@@ -90,3 +90,29 @@ def test_generated_kernel_arithmetic_matches_the_reference_goldens(n, tmp_path, 
     fn = build_host_kernel(model, "elim", tmp_path, monkeypatch)
     post, single, st = run_host(fn, model, case.lk, case.flags)
     check(case, post, single, st, rtol=1e-10)
+
+
+def test_a_pedigree_wider_than_lds_rows_could_stage(tmp_path, monkeypatch):
+    """128 members: 3N doubles per lane would be 197 KB of LDS per wave — the generated kernel is the form without LDS
+    staging (variant 8), here compiled for the host and checked against the numpy oracle (itself pinned to the reference's
+    -method 2 on the 24 / 32 / 48-member goldens)."""
+    from famseq_amd.prebuild_sets import wide_pedigree
+    from test_generated_host import build_host_kernel, run_host
+
+    ped = wide_pedigree(128)
+    rng = np.random.RandomState(128)
+    pl = rng.randint(0, 120, size=(40, ped.n, 3)).astype(float)
+    pl[np.arange(40)[:, None], np.arange(ped.n)[None, :], rng.randint(0, 3, size=(40, ped.n))] = 0
+    lk = 10.0 ** (-pl / 10.0)
+    lk[:, ped.sequenced == 0, :] = 1.0
+    flags = rng.randint(0, 4, 40).astype(np.uint8)
+    want = sp.pedigree_posterior(ped, lk, flags)
+    assert np.all(want[2] == 0)
+    model = fs.make_model(ped)
+    probe = fs.Context(model, device=-1)
+    assert probe.plan()["elim_variant"] >= 8
+    probe.close()
+    fn = build_host_kernel(model, "elim", tmp_path, monkeypatch)
+    post, single, st = run_host(fn, model, lk, flags)
+    assert np.array_equal(st, want[2]) and np.array_equal(single, want[1])
+    np.testing.assert_allclose(post, want[0], rtol=1e-9, atol=1e-300)
