@@ -145,8 +145,8 @@ class Emitter {
  public:
   // out: where the normalised marginals go — "q" (registers: the shell's compute-first flow) or "row" (the lane's LDS row,
   // free once the likelihoods sit in registers: the shell's registers-first flow)
-  Emitter(const Model &m, const Graph &g, int fences, bool scalar_t, const char *out = "q")
-      : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t), out_(out) {}
+  Emitter(const Model &m, const Graph &g, int fences, bool scalar_t, const char *out = "q", bool lean = false)
+      : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t), out_(out), lean_(lean) {}
 
   std::string body() {
     if (g_.cut.empty()) {
@@ -222,6 +222,7 @@ class Emitter {
   const int fences_;  // 0 none, 1 after every family->member message, 2 also after local factors and child sums
   const bool scalar_t_;  // transmission entries from tcx[] (uniform pointer: scalar loads) instead of the lane's LDS table
   const std::string out_;
+  const bool lean_;  // local factors re-formed at each use (see loc)
   std::ostringstream o_;
   std::map<std::string, bool> done_;
   int uid_ = 0;
@@ -255,9 +256,13 @@ class Emitter {
         std::string e = "l" + num(p) + "_" + num(g);
         if (m_.mother[p] < 0) e = "(tcf[" + num(kind(p) * 27 + 9 * g) + "] * " + e + ")";
         if (scale) e = "(10000000.0 * " + e + ")";
-        o_ << "      const double " << n << "_" << g << " = " << e << ";\n";
+        // lean: not a variable but a macro — the factor is formed again at each of its two or three uses, from a fresh read of
+        // the likelihood, instead of living in a register from the first use to the last (3N doubles: the widest pedigrees'
+        // register wall)
+        if (lean_) o_ << "#define " << n << "_" << g << " " << e << "\n";
+        else o_ << "      const double " << n << "_" << g << " = " << e << ";\n";
       }
-      fence(2);
+      if (!lean_) fence(2);
     }
     return n;
   }
@@ -788,14 +793,18 @@ namespace {
 // instruction, a cache line per lane.  What the staged shell buys with its LDS rows (coalesced 16-byte accesses) costs it
 // the CU's LDS: 3N doubles per lane leave two waves per CU at 48 members and nothing beyond about a hundred; this form
 // needs 3.4 KB of LDS (the factor tables) whatever N is, runs four waves per CU, and has no barrier after the first.
-std::string direct_shell(const Model &m, const std::string &comment, const std::string &body, int bt, bool fence_single, bool chrx_loop) {
+std::string direct_shell(const Model &m, const std::string &comment, const std::string &body, int bt, bool fence_single, bool chrx_loop,
+                         bool lean) {
   const int N = m.n_members, W3 = 3 * N;
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n#pragma clang fp contract(off)\n"
     << "#define W3 " << W3 << "\n#define BT " << bt << "\n"
-    << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
-    << "extern \"C\" __global__ __launch_bounds__(BT, 1) void famseq_elim(const double *__restrict__ lk_g,\n"
+    << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n";
+  if (lean)  // a likelihood is read from the lane's row in global memory at each use (volatile: never kept in a register)
+    for (int p = 0; p < N; ++p)
+      for (int gt = 0; gt < 3; ++gt) s << "#define l" << p << "_" << gt << " lgv[" << 3 * p + gt << "]\n";
+  s << "extern \"C\" __global__ __launch_bounds__(BT, 1) void famseq_elim(const double *__restrict__ lk_g,\n"
     << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
     << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
     << "  __shared__ double s_tc[432];\n"
@@ -815,8 +824,11 @@ std::string direct_shell(const Model &m, const std::string &comment, const std::
     << "    const int fl = flags_g ? (flags_g[site] & 3) : 0;\n"
     << "    const double *tcf = s_tc + fl * 108;\n"
     << "    bool single_fail = false, full = false, bn_fail = false;\n";
-  for (int p = 0; p < N; ++p)
-    for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = lg[" << 3 * p + gt << "];\n";
+  if (lean)
+    s << "    typedef const volatile __attribute__((address_space(1))) double glb_cvd;\n    glb_cvd *lgv = (glb_cvd *)lg;\n";
+  else
+    for (int p = 0; p < N; ++p)
+      for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = lg[" << 3 * p + gt << "];\n";
   s << single_posterior_statements(m, true, true, fence_single)
     << "    if (single_fail) {\n#pragma unroll 1\n      for (int k = 0; k < W3; ++k) row[k] = kNaN;\n    }\n"
     // a site that does not take the full computation: its posterior IS the single posterior (family.cpp:793-878) or NaN
@@ -847,11 +859,14 @@ std::string elim_source(const Model &m, int variant, bool call_mode) {
   if (!build_graph(m, g, &why)) throw std::runtime_error("elimination engine: " + why);
   if (variant >= 8 && !call_mode) {  // no LDS staging: see direct_shell
     const int f = variant & 3;
+    bool lean = false;
+    if (const char *e = std::getenv("FAMSEQ_ELIM_LEAN")) lean = std::atoi(e) != 0;  // tuning aid
     return direct_shell(m,
                         "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families" +
                             (g.cut.empty() ? "" : ", conditioned on " + std::to_string(g.cut.size()) + " member(s)") + ", variant " +
                             std::to_string(variant) + " (rows straight from and to global memory)",
-                        Emitter(m, g, f < 2 ? f : 2, /*scalar_t=*/f >= 1, "pg").body(), elim_block_threads(m, false), f >= 3, /*chrx_loop=*/f >= 1);
+                        Emitter(m, g, f < 2 ? f : 2, /*scalar_t=*/f >= 1, "pg", lean).body(), elim_block_threads(m, false), f >= 3, /*chrx_loop=*/f >= 1,
+                        lean);
   }
   const int bt = elim_block_threads(m, call_mode);
   int min_waves = call_mode && m.n_members <= 10 ? 2 : 1;

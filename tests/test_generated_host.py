@@ -97,7 +97,7 @@ def host_source(src: str, threads=False) -> str:
     src = src.replace("#include <hip/hip_runtime.h>", SHIM + (SHIM_CALL if "fs_call_args" in src else ""))
     src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() (void)0", src)
     src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "")
-    src = src.replace("__attribute__((address_space(3)))", "")
+    src = src.replace("__attribute__((address_space(3)))", "").replace("__attribute__((address_space(1)))", "")
     src = re.sub(r'asm volatile\(""[^\n;]*\);', "", src)  # compiler pins / fences: no arithmetic in them
     assert "asm" not in src
     return src
@@ -437,7 +437,7 @@ def _threaded_call_kernel(model, elim, bt, cache, monkeypatch):
     src = re.sub(r"#define FS_KEEP_BRANCH\(\) asm.*", "", src).replace("typedef double fs_v2d __attribute__((ext_vector_type(2)));", "")
     src = src.replace("#include <hip/hip_runtime.h>", shim).replace("__builtin_amdgcn_sched_barrier(0);", "")
     src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() pthread_barrier_wait(&wg_barrier_)", src)
-    src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "").replace("__attribute__((address_space(3)))", "")
+    src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "").replace("__attribute__((address_space(3)))", "").replace("__attribute__((address_space(1)))", "")
     src = re.sub(r'asm volatile\(""[^\n;]*\);', "", src.replace('extern "C" __global__', "static"))
     src += """
 #undef %(e)s
