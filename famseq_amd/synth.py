@@ -243,8 +243,12 @@ def grow_pedigree(rng, n, allow_loops):
     return Pedigree(ids, mids, fids, gen, names)
 
 
-def random_likelihoods(rng, ped, n_sites):
-    pl = rng.randint(0, 300, size=(n_sites, ped.n, 3)).astype(float)
+def random_likelihoods(rng, ped, n_sites, max_pl=300):
+    """Adversarial rows: PLs uniform in [0, max_pl) with no regard for Mendelian consistency, hard zeros, sites sharp enough
+    for the -LRC shortcut, flags 0..3.  (Wide pedigrees want a smaller max_pl: fifty members that each contradict their
+    parents at 1e-15 a piece put the whole site's probability mass below 1e-308, where every implementation's digits are
+    what gradual underflow leaves of them.)"""
+    pl = rng.randint(0, max_pl, size=(n_sites, ped.n, 3)).astype(float)
     pl[np.arange(n_sites)[:, None], np.arange(ped.n)[None, :], rng.randint(0, 3, size=(n_sites, ped.n))] = 0
     lk = 10.0 ** (-pl / 10.0)
     lk[rng.rand(n_sites, ped.n, 3) < 0.02] = 0.0           # hard zeros
