@@ -51,7 +51,9 @@ inline char *g6(char *out, double v) {
   {
     double x = v * kPow10d[5 - X];
     if (x < 100000.0 - 1e-6) --X, x = v * kPow10d[5 - X];
-    const double r = std::nearbyint(x);
+    // nearest integer of a positive x < 2^52 as (x + 2^52) - 2^52 in the default rounding mode: two additions instead of a
+    // libm call (without -msse4.1 std::nearbyint is one); a tie would be rounded to even, but ties are excluded just below
+    const double r = (x + 4503599627370496.0) - 4503599627370496.0;
     if (x > 100000.0 + 1e-6 && std::fabs(x - r) < 0.5 - 1e-6) {
       digits = uint64_t(r);
       if (digits == 1000000) {
