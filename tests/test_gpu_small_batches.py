@@ -86,3 +86,22 @@ def test_group_size_follows_the_batch_size():
     trio = fs.Context(fs.make_model(fs.synthetic_pedigree("trio")))
     assert trio.plan()["enum_group_digits_max"] == 0
     trio.close()
+
+
+def test_a_tiny_batch_takes_the_generated_kernel_only_when_nothing_has_to_be_compiled(tmp_path, monkeypatch):
+    """Below "lane_min_sites" (256) the compiled-in team kernel used to answer every call, so that a tiny call never waits
+    for a per-pedigree compile.  Since round 3 the generated kernel serves such a call too when its code object is loaded
+    or on disk already (the pre-built pedigrees; anything this user has run before) — and still not otherwise."""
+    ped = fs.synthetic_pedigree("ped10")
+    mo, fa = ped.relations()
+    lk, flags = fs.synth.gen_batch(mo, fa, 40, 2)
+    ref = oracle.OracleModel(ped.ids, ped.mids, ped.fids, ped.genders).bn_batch(lk, flags)
+    ctx = fs.Context(fs.make_model(ped))  # defaults; the in-tree cache holds ped10's kernels (build())
+    check(ctx.bn_batch(lk, flags), ref, "cached")
+    assert ctx.plan()["enum_group_digits_last"] == 4  # 81 lanes per site served it
+    ctx.close()
+    monkeypatch.setenv("FAMSEQ_KERNEL_CACHE", str(tmp_path))  # an empty cache: the same call must not compile anything
+    ctx = fs.Context(fs.make_model(ped))
+    check(ctx.bn_batch(lk, flags), ref, "uncached")
+    assert ctx.plan()["enum_group_digits_last"] == 0 and not any(f.name.endswith(".hsaco") for f in tmp_path.iterdir())
+    ctx.close()
