@@ -116,3 +116,4 @@ def test_a_pedigree_wider_than_lds_rows_could_stage(tmp_path, monkeypatch):
     post, single, st = run_host(fn, model, lk, flags)
     assert np.array_equal(st, want[2]) and np.array_equal(single, want[1])
     np.testing.assert_allclose(post, want[0], rtol=1e-9, atol=1e-300)
+
