@@ -215,6 +215,20 @@ def test_bench_launches_its_own_ranks(scaling):
     assert out["roofline"]["frac"] > 0
 
 
+def test_multi_rank_bench_line_carries_the_strong_scaling_case():
+    """For N > 1 the headline (weak scaling, BASELINE configs[2] per GPU) comes with `configs_3_strong`: configs[3] read
+    literally — 10 M ten-member sites in total, sharded — timed by the same ranks; plus every rank's verdict on its outputs and
+    the world size the backend reports.  (Here: two ranks sharing the one GPU, 300 k resident sites each, so each rank's share
+    of the 10 M is capped by what it holds.)"""
+    share = [] if fs.device_count() >= 2 else ["--share-gpu"]
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--sites", "300000", "--no-cpu-baseline", "--no-elim"] + share)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["per_rank_outputs_valid"] == [True, True]
+    assert out["config"]["world_size_reported_by_backend"] == 2
+    st = out["configs_3_strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["value"] > 0 and st["per_rank_outputs_valid"] == [True, True]
+    assert st["sites_per_gpu"] == 300000 and st["global_sites"] == 600000
+
+
 def test_tune_times_the_variants_and_later_contexts_start_from_the_pick(tmp_path, monkeypatch):
     """famseq_set_option "tune": the candidates of a pedigree's generated kernels are timed on this GPU and the winners'
     indices kept as notes in the kernel cache; results stay what they were; a later context compiles the picked variant
