@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <future>
 #include <iostream>
 #include <charconv>
@@ -1406,6 +1407,17 @@ bool run_vcf(const Options &o, const Ped &ped) {
   unsigned n_threads = std::thread::hardware_concurrency();
   if (const char *e = std::getenv("FAMSEQ_THREADS")) n_threads = (unsigned)std::atoi(e);
   n_threads = std::max(1u, std::min(n_threads, 32u));
+  // A block is cut into n_threads parts; how many threads walk them while parsing and while formatting can be set apart
+  // (formatting is the loop's critical path and runs beside the next block's parsing: tools/cli_throughput.py)
+  unsigned parse_threads = n_threads, format_threads = n_threads;
+  if (const char *e = std::getenv("FAMSEQ_PARSE_THREADS")) parse_threads = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("FAMSEQ_FORMAT_THREADS")) format_threads = std::max(1, std::atoi(e));
+  auto on_parts = [](int n_parts, unsigned threads, const std::function<void(int)> &f) {
+    const int nt = (int)std::min<unsigned>(threads, (unsigned)n_parts);
+    on_threads(nt, [&](int j) {
+      for (int t = j; t < n_parts; t += nt) f(t);
+    });
+  };
   struct Slot {
     vector<std::string_view> lines;
     vector<Part> parts;
@@ -1418,14 +1430,14 @@ bool run_vcf(const Options &o, const Ped &ped) {
     PlBatch io;          // pinned: pl + flags in, gpp / fpp / fgt / status out
     vector<double> lk;   // fp64 input, only for a block with a non-integer PL/GL field
     vector<TextBuf> text;
-  } slots[3];  // one being cut and parsed, one at the GPU / being formatted, one being written
+  } slots[4];  // one being cut and parsed, one at the GPU, one being formatted, one being written
   bool ok = true;
   for (Slot &sl : slots) sl.parts.resize(n_threads), sl.text.resize(n_threads);
 
   double t_lines = 0, t_parse = 0, t_gather = 0, t_stall = 0, t_gpu = 0, t_format = 0, t_write = 0, t_ctx_wait = 0;
   int compact_from = 12;  // members from which a block's sites are moved together before the GPU call (below)
   if (const char *e = std::getenv("FAMSEQ_COMPACT_FROM")) compact_from = std::atoi(e);  // test aid
-  Channel to_flusher, to_writer, to_driver;
+  Channel to_flusher, to_formatter, to_writer, to_driver;
   std::atomic<bool> flush_ok{true};
   std::thread flusher([&] {
     for (;;) {
@@ -1463,10 +1475,21 @@ bool run_vcf(const Options &o, const Ped &ped) {
           flush_ok = false;
         }
       }
+      t_gpu += now_s() - t0;
+      to_formatter.put(i);
+    }
+    to_formatter.put(-1);
+  });
+  // ... the results are turned into text on their own thread (and its helpers) while the next block is at the GPU ...
+  std::thread formatter([&] {
+    for (;;) {
+      const int i = to_formatter.take();
+      if (i < 0) break;
+      Slot &sl = slots[i];
+      const size_t k = n_seq;
       const double t1 = now_s();
-      t_gpu += t1 - t0;
       if (flush_ok) {
-        on_threads(sl.n_parts, [&](int t) {
+        on_parts(sl.n_parts, format_threads, [&](int t) {
           Part &pt = sl.parts[t];
           TextBuf &out = sl.text[t];
           out.n = 0;
@@ -1536,7 +1559,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
   });
 
   const double t_begin = now_s();
-  to_driver.put(0), to_driver.put(1), to_driver.put(2);
+  to_driver.put(0), to_driver.put(1), to_driver.put(2), to_driver.put(3);
   bool more = have_line;
   while (more && ok && flush_ok) {
     double t0 = now_s();
@@ -1576,7 +1599,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
     }
     uint16_t *const pl_arr = o.pack_mode || sl.staged ? sl.pk_pl.data() : sl.io.pl;
     uint8_t *const flags_arr = o.pack_mode || sl.staged ? sl.pk_flags.data() : sl.io.flags;
-    on_threads(sl.n_parts, [&](int t) {
+    on_parts(sl.n_parts, parse_threads, [&](int t) {
       Part &pt = sl.parts[t];
       pt.clear();
       const size_t lo = nl * t / sl.n_parts, hi = nl * (t + 1) / sl.n_parts;
@@ -1660,6 +1683,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
   }
   to_flusher.put(-1);
   flusher.join();
+  formatter.join();
   writer.join();
   if (!ctx && ctx_future.valid()) ctx = ctx_future.get();  // a file without a single data line: nobody asked for it yet
   ok = ok && flush_ok && (o.pack_mode || ctx);
