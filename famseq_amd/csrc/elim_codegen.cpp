@@ -145,8 +145,8 @@ class Emitter {
  public:
   // out: where the normalised marginals go — "q" (registers: the shell's compute-first flow) or "row" (the lane's LDS row,
   // free once the likelihoods sit in registers: the shell's registers-first flow)
-  Emitter(const Model &m, const Graph &g, int fences, bool scalar_t, const char *out = "q", bool lean = false)
-      : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t), out_(out), lean_(lean) {}
+  Emitter(const Model &m, const Graph &g, int fences, bool scalar_t, const char *out = "q", bool lean = false, int lean_from = 1 << 30)
+      : m_(m), g_(g), fences_(fences), scalar_t_(scalar_t), out_(out), lean_(lean), lean_from_(lean_from) {}
 
   std::string body() {
     if (g_.cut.empty()) {
@@ -223,6 +223,7 @@ class Emitter {
   const bool scalar_t_;  // transmission entries from tcx[] (uniform pointer: scalar loads) instead of the lane's LDS table
   const std::string out_;
   const bool lean_;  // local factors re-formed at each use (see loc)
+  const int lean_from_;  // ... for members lean_from_ and above only (their likelihoods sit in the lane's LDS row: direct_shell)
   std::ostringstream o_;
   std::map<std::string, bool> done_;
   int uid_ = 0;
@@ -259,10 +260,10 @@ class Emitter {
         // lean: not a variable but a macro — the factor is formed again at each of its two or three uses, from a fresh read of
         // the likelihood, instead of living in a register from the first use to the last (3N doubles: the widest pedigrees'
         // register wall)
-        if (lean_) o_ << "#define " << n << "_" << g << " " << e << "\n";
+        if (lean_ || p >= lean_from_) o_ << "#define " << n << "_" << g << " " << e << "\n";
         else o_ << "      const double " << n << "_" << g << " = " << e << ";\n";
       }
-      if (!lean_) fence(2);
+      if (!(lean_ || p >= lean_from_)) fence(2);
     }
     return n;
   }
@@ -794,8 +795,11 @@ namespace {
 // the CU's LDS: 3N doubles per lane leave two waves per CU at 48 members and nothing beyond about a hundred; this form
 // needs 3.4 KB of LDS (the factor tables) whatever N is, runs four waves per CU, and has no barrier after the first.
 std::string direct_shell(const Model &m, const std::string &comment, const std::string &body, int bt, bool fence_single, bool chrx_loop,
-                         bool lean) {
-  const int N = m.n_members, W3 = 3 * N;
+                         bool lean, int lds_from) {
+  // lds_from: members lds_from .. N-1 keep their likelihoods in a per-lane LDS row (3 doubles each, odd stride) and are read
+  // from there at each use; the others live in registers.  The last members' local factors have the longest live ranges (the
+  // upward pass of the first marginal touches every member, and member p's factor is needed again at its own marginal).
+  const int N = m.n_members, W3 = 3 * N, n_lds = lds_from < N ? N - lds_from : 0, LP = (3 * n_lds) | 1;
   std::ostringstream s;
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n#pragma clang fp contract(off)\n"
@@ -804,13 +808,20 @@ std::string direct_shell(const Model &m, const std::string &comment, const std::
   if (lean)  // a likelihood is read from the lane's row in global memory at each use (volatile: never kept in a register)
     for (int p = 0; p < N; ++p)
       for (int gt = 0; gt < 3; ++gt) s << "#define l" << p << "_" << gt << " lgv[" << 3 * p + gt << "]\n";
+  else
+    for (int p = lds_from; p < N; ++p)
+      for (int gt = 0; gt < 3; ++gt) s << "#define l" << p << "_" << gt << " lrow[" << 3 * (p - lds_from) + gt << "]\n";
   s << "extern \"C\" __global__ __launch_bounds__(BT, 1) void famseq_elim(const double *__restrict__ lk_g,\n"
     << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
     << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
     << "  __shared__ double s_tc[432];\n"
     << "  const int tid = threadIdx.x;\n"
-    << "  for (int i = tid; i < 432; i += BT) s_tc[i] = tc_g[i];\n"
-    << "  LDS_BARRIER();\n"
+    << "  for (int i = tid; i < 432; i += BT) s_tc[i] = tc_g[i];\n";
+  if (n_lds > 0)
+    s << "  __shared__ double s_l[BT * " << LP << "];  // the last " << n_lds << " members' likelihoods, one padded row per lane\n"
+      << "  typedef const volatile __attribute__((address_space(3))) double lds_cvd;\n"
+      << "  double *lw = s_l + tid * " << LP << ";\n  lds_cvd *lrow = (lds_cvd *)lw;\n";
+  s << "  LDS_BARRIER();\n"
     << "  const long chunks = (n_sites + BT - 1) / BT;\n"
     << "  const long q_wg = chunks / gridDim.x, r_wg = chunks - q_wg * gridDim.x;\n"
     << "  const long c_lo = (long)blockIdx.x * q_wg + (blockIdx.x < r_wg ? blockIdx.x : r_wg), c_hi = c_lo + q_wg + (blockIdx.x < r_wg ? 1 : 0);\n"
@@ -826,9 +837,11 @@ std::string direct_shell(const Model &m, const std::string &comment, const std::
     << "    bool single_fail = false, full = false, bn_fail = false;\n";
   if (lean)
     s << "    typedef const volatile __attribute__((address_space(1))) double glb_cvd;\n    glb_cvd *lgv = (glb_cvd *)lg;\n";
-  else
-    for (int p = 0; p < N; ++p)
+  else {
+    for (int p = 0; p < std::min(N, lds_from); ++p)
       for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = lg[" << 3 * p + gt << "];\n";
+    for (int k = 3 * std::min(N, lds_from); k < W3; ++k) s << "    lw[" << k - 3 * lds_from << "] = lg[" << k << "];\n";
+  }
   s << single_posterior_statements(m, true, true, fence_single)
     << "    if (single_fail) {\n#pragma unroll 1\n      for (int k = 0; k < W3; ++k) row[k] = kNaN;\n    }\n"
     // a site that does not take the full computation: its posterior IS the single posterior (family.cpp:793-878) or NaN
@@ -861,12 +874,18 @@ std::string elim_source(const Model &m, int variant, bool call_mode) {
     const int f = variant & 3;
     bool lean = false;
     if (const char *e = std::getenv("FAMSEQ_ELIM_LEAN")) lean = std::atoi(e) != 0;  // tuning aid
+    // members whose likelihoods live in the lane's LDS row rather than in registers: at four waves per CU a lane has 73 doubles
+    // of LDS, 24 members.  Pays from the mid-fifties on, where the scratch it spares outweighs the LDS latency it adds (2 M
+    // sites: 48 members 2.37-2.50 -> 2.55-2.59 ms, 64: 4.72-4.91 -> 4.25-4.44, 96: 10.3-10.5 -> 9.07; scratch 1276 -> 956 B at 64)
+    int n_lds = m.n_members >= 56 ? 24 : 0;
+    if (const char *e = std::getenv("FAMSEQ_ELIM_LDSL")) n_lds = std::max(0, std::min(std::atoi(e), m.n_members));  // tuning aid
+    const int lds_from = lean ? m.n_members : m.n_members - n_lds;
     return direct_shell(m,
                         "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families" +
                             (g.cut.empty() ? "" : ", conditioned on " + std::to_string(g.cut.size()) + " member(s)") + ", variant " +
                             std::to_string(variant) + " (rows straight from and to global memory)",
-                        Emitter(m, g, f < 2 ? f : 2, /*scalar_t=*/f >= 1, "pg", lean).body(), elim_block_threads(m, false), f >= 3, /*chrx_loop=*/f >= 1,
-                        lean);
+                        Emitter(m, g, f < 2 ? f : 2, /*scalar_t=*/f >= 1, "pg", lean, lds_from).body(), elim_block_threads(m, false), f >= 3,
+                        /*chrx_loop=*/f >= 1, lean, lds_from);
   }
   const int bt = elim_block_threads(m, call_mode);
   int min_waves = call_mode && m.n_members <= 10 ? 2 : 1;
