@@ -77,7 +77,9 @@ std::string cache_dir() {
   if (const char *e = std::getenv("FAMSEQ_KERNEL_CACHE"))
     if (writable_dir(e)) return e;
   const std::string in_tree = lib_dir() + "/kernels";
-  if (writable_dir(in_tree)) return in_tree;
+  // ($FAMSEQ_LIBDIR_READONLY: treat the library's directory as read-only — what a packaged installation is; a test aid,
+  // because root, who runs the CPU suite, can write everywhere)
+  if (!std::getenv("FAMSEQ_LIBDIR_READONLY") && writable_dir(in_tree)) return in_tree;
   const std::string tmp = "/tmp/famseq_kernels_" + std::to_string((long)getuid());
   if (private_dir(tmp)) return tmp;
   throw std::runtime_error("no usable kernel cache directory (" + in_tree + " is not writable and " + tmp +

@@ -82,7 +82,6 @@ print('ok')
     assert "ok" in run_py(code, {"FAMSEQ_KERNEL_CACHE": str(cache)}, tmp_path)
 
 
-@pytest.mark.skipif(os.geteuid() == 0, reason="root ignores directory permissions: a read-only library directory cannot be staged")
 def test_a_local_tuning_note_overrides_the_shipped_one(tmp_path):
     """A deployment whose library directory is read-only and ships a pick: the user's own note lands in the per-user
     cache and is the one read back."""
@@ -111,9 +110,13 @@ print(c.plan()['elim_variant'])
 
     assert run("pick_elim", "1") == "1"          # written into lib/kernels (still writable): the "shipped" pick
     os.chmod(lib / "kernels", 0o555)
+    env["FAMSEQ_LIBDIR_READONLY"] = "1"           # (root ignores the mode bits: say it in words as well)
     try:
         assert run("pick_elim", "0") == "0"      # lands in /tmp/famseq_kernels_<uid> and wins over the shipped 1
+        # ... and a context that sets nothing reads the local note, not the shipped one
+        script.write_text(code.replace("c.set_option(sys.argv[2], int(sys.argv[3]))", "pass"))
+        assert run("-", "0") == "0"
     finally:
         os.chmod(lib / "kernels", 0o755)
-        for f in glob.glob("/tmp/famseq_kernels_%d/*.pick" % os.getuid()):
+        for f in glob.glob("/tmp/famseq_kernels_%d/*" % os.getuid()):
             os.unlink(f)
