@@ -811,7 +811,9 @@ std::string direct_shell(const Model &m, const std::string &comment, const std::
   else
     for (int p = lds_from; p < N; ++p)
       for (int gt = 0; gt < 3; ++gt) s << "#define l" << p << "_" << gt << " lrow[" << 3 * (p - lds_from) + gt << "]\n";
-  s << "extern \"C\" __global__ __launch_bounds__(BT, 1) void famseq_elim(const double *__restrict__ lk_g,\n"
+  int min_waves = 1;
+  if (const char *e = std::getenv("FAMSEQ_ELIM_MINWAVES")) min_waves = std::max(1, std::atoi(e));  // tuning aid
+  s << "extern \"C\" __global__ __launch_bounds__(BT, " << min_waves << ") void famseq_elim(const double *__restrict__ lk_g,\n"
     << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
     << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc) {\n"
     << "  __shared__ double s_tc[432];\n"
