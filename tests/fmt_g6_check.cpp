@@ -24,6 +24,15 @@ static void check(double v) {
   std::snprintf(b, sizeof b, "%g", v);
   ++g_n;
   if (std::strcmp(a, b) != 0 && g_bad++ < 20) std::printf("MISMATCH %.17g: g6 '%s' printf '%s'\n", v, a, b);
+  // the byte-by-byte layout the device text kernel uses (csrc/g6_core.h), over its domain: 0 and [1e-16, 1e6) short of the
+  // carry into 1e6
+  if ((v == 0 && !std::signbit(v)) || (v >= 1e-16 && v < 999999.5)) {
+    unsigned char c[64];
+    std::memset(c, '#', sizeof c);
+    const int n = famseq_g6::g6_phred(c, v);
+    if ((n != (int)std::strlen(b) || std::memcmp(c, b, (size_t)n) != 0 || c[n] != '#' || n > 11) && g_bad++ < 20)
+      std::printf("MISMATCH %.17g: g6_phred '%.*s' printf '%s'\n", v, n, (const char *)c, b);
+  }
 }
 
 int main(int argc, char **argv) {
