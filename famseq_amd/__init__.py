@@ -23,6 +23,7 @@ from .pedigree import Pedigree, read_ped, synthetic_pedigree  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libfamseq_hip.so")
 MAXN = 20
+TEXT_STRIDE = 80  # FAMSEQ_TEXT_STRIDE
 
 ST_OK, ST_SINGLE_FAIL, ST_BN_FAIL, ST_SHORTCUT = 0, 1, 2, 0x80
 FLAG_KNOWN, FLAG_CHRX = 1, 2
@@ -78,7 +79,7 @@ ABI_SYMBOLS = [
     "famseq_create_pedigree",
     "famseq_destroy", "famseq_last_error", "famseq_set_option", "famseq_plan_json",
     "famseq_bn_batch", "famseq_bn_batch_sharded", "famseq_bn_batch_device", "famseq_bn_batch_device_sharded",
-    "famseq_bn_call_batch", "famseq_alloc_pinned", "famseq_free_pinned", "famseq_stream_probe",
+    "famseq_bn_call_batch", "famseq_bn_call_text_batch", "famseq_format_probe", "famseq_alloc_pinned", "famseq_free_pinned", "famseq_stream_probe",
     "famseq_call_genotypes",
 ]
 PL_MISSING = 0xFFFF
@@ -137,6 +138,10 @@ def lib():
     L.famseq_bn_call_batch.argtypes = [C.c_void_p, C.c_int64, dp, C.POINTER(C.c_uint16), bp, ip, C.c_int32, dp, dp,
                                        C.POINTER(C.c_int8), bp]
     L.famseq_bn_call_batch.restype = C.c_int
+    L.famseq_bn_call_text_batch.argtypes = [C.c_void_p, C.c_int64, dp, C.POINTER(C.c_uint16), bp, ip, C.c_int32, C.c_char_p, bp]
+    L.famseq_bn_call_text_batch.restype = C.c_int
+    L.famseq_format_probe.argtypes = [C.c_void_p, C.c_int64, dp, C.c_char_p]
+    L.famseq_format_probe.restype = C.c_int
     L.famseq_stream_probe.argtypes = [C.c_void_p, C.c_int64, vp, vp, vp, vp]
     L.famseq_stream_probe.restype = C.c_int
     L.famseq_alloc_pinned.argtypes = [C.c_size_t]
@@ -266,6 +271,36 @@ class Context:
                                         _p(gpp, C.c_double), _p(fpp, C.c_double), _p(fgt, C.c_int8), _p(status, C.c_uint8))
         self._check(rc, "famseq_bn_call_batch")
         return gpp, fpp, fgt, status
+
+    def bn_call_text_batch(self, seq_members, lk=None, pl16=None, flags=None):
+        """The call path with its outputs as text: -> (records, status).  records[s][j] is the bytes the reference's drivers
+        append to sample column j of site s, b"g0,g1,g2:f0,f1,f2:0/1\\t" (file.cpp:696-745), formatted on the device."""
+        seq = np.ascontiguousarray(seq_members, dtype=np.int32)
+        k = len(seq)
+        if (lk is None) == (pl16 is None):
+            raise ValueError("give exactly one of lk / pl16")
+        if lk is not None:
+            lk = np.ascontiguousarray(lk, dtype=np.float64).reshape(-1, self.n, 3)
+            s = lk.shape[0]
+        else:
+            pl16 = np.ascontiguousarray(pl16, dtype=np.uint16).reshape(-1, k, 3)
+            s = pl16.shape[0]
+        fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
+        text = np.zeros((s, k, TEXT_STRIDE), np.uint8)
+        status = np.zeros(s, np.uint8)
+        rc = lib().famseq_bn_call_text_batch(self._h, s, None if lk is None else _p(lk, C.c_double),
+                                             None if pl16 is None else _p(pl16, C.c_uint16),
+                                             None if fl is None else _p(fl, C.c_uint8), _p(seq, C.c_int32), k,
+                                             text.ctypes.data_as(C.c_char_p), _p(status, C.c_uint8))
+        self._check(rc, "famseq_bn_call_text_batch")
+        return text, status
+
+    def g6_probe(self, values):
+        """The device formatter alone (famseq_format_probe): -> list of bytes, one per value."""
+        v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        out = np.zeros((len(v), 16), np.uint8)
+        self._check(lib().famseq_format_probe(self._h, len(v), _p(v, C.c_double), out.ctypes.data_as(C.c_char_p)), "famseq_format_probe")
+        return [bytes(r[:r[15]]) for r in out]
 
     def bn_batch_device(self, n_sites, d_lk, d_flags, d_post, d_single=0, d_status=0, stream=0):
         """Raw device pointers (ints); enqueues on `stream` and returns."""

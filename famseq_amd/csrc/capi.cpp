@@ -100,6 +100,7 @@ struct famseq_ctx {
   uint16_t *d_pl[kSlots] = {};
   double *d_gpp[kSlots] = {}, *d_fpp[kSlots] = {};
   int8_t *d_fgt[kSlots] = {};
+  char *d_text[kSlots] = {};  // text records of the called outputs (famseq_bn_call_text_batch)
   double *d_lut = nullptr;
   int32_t *d_seq = nullptr, *d_col = nullptr;
   CallIO *d_call[kSlots] = {};  // the generated kernels' call-path arguments, one per slot
@@ -166,11 +167,13 @@ void free_slots(famseq_ctx *c) {
     if (c->d_gpp[s]) (void)hipFree(c->d_gpp[s]);
     if (c->d_fpp[s]) (void)hipFree(c->d_fpp[s]);
     if (c->d_fgt[s]) (void)hipFree(c->d_fgt[s]);
+    if (c->d_text[s]) (void)hipFree(c->d_text[s]);
     c->d_lk[s] = c->d_post[s] = c->d_single[s] = nullptr;
     c->d_flags[s] = c->d_status[s] = nullptr;
     c->d_pl[s] = nullptr;
     c->d_gpp[s] = c->d_fpp[s] = nullptr;
     c->d_fgt[s] = nullptr;
+    c->d_text[s] = nullptr;
   }
   c->slot_sites = 0;
   c->slot_seq = 0;
@@ -876,6 +879,7 @@ struct HostIO {
   uint8_t *status = nullptr;
   double *gpp = nullptr, *fpp = nullptr;  // called outputs [n_sites][n_seq][3]
   int8_t *fgt = nullptr;                  // [n_sites][n_seq]
+  char *text = nullptr;                   // the same three as printed: [n_sites][n_seq][FAMSEQ_TEXT_STRIDE]
 };
 
 // Upload the sequenced-member list (VCF column order) and its inverse when it changes.
@@ -907,7 +911,7 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
   HIP_TRY(c, hipSetDevice(c->device));
   const int N = c->model.n_members;
   const size_t row = size_t(3) * N * sizeof(double);
-  const bool called = io.gpp || io.fpp || io.fgt;
+  const bool called = io.gpp || io.fpp || io.fgt || io.text;
   // default chunk: at most 64 MiB per array, at least four chunks per call so that the stages overlap,
   // but not below the batch size the lane-per-site kernel needs to fill the chip
   int64_t chunk = c->chunk_sites;
@@ -932,6 +936,7 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_gpp[s]), cap * seqcap * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_fpp[s]), cap * seqcap * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_fgt[s]), cap * seqcap));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_text[s]), cap * seqcap * size_t(kTextStride)));
         if (!c->d_call[s]) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_call[s]), sizeof(CallIO)));
       }
     }
@@ -954,9 +959,9 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
       cio.lut = c->d_lut;
       cio.col = c->d_col;
       cio.seq = c->d_seq;
-      cio.gpp = io.gpp ? c->d_gpp[s] : nullptr;
-      cio.fpp = io.fpp ? c->d_fpp[s] : nullptr;
-      cio.fgt = io.fgt ? c->d_fgt[s] : nullptr;
+      cio.gpp = io.gpp || io.text ? c->d_gpp[s] : nullptr;
+      cio.fpp = io.fpp || io.text ? c->d_fpp[s] : nullptr;
+      cio.fgt = io.fgt || io.text ? c->d_fgt[s] : nullptr;
       cio.n_seq = n_seq;
       // e / d for e < 2^16, d <= 60 as the high word of e * (2^32 / d + 1): exact (io_kernels.hip)
       cio.magic_w = 0xFFFFFFFFu / uint32_t(3 * n_seq) + 1;
@@ -977,7 +982,7 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
 int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int64_t chunk) {
   const int N = c->model.n_members;
   const size_t row = size_t(3) * N * sizeof(double);
-  const bool called = io.gpp || io.fpp || io.fgt;
+  const bool called = io.gpp || io.fpp || io.fgt || io.text;
   hipStream_t s_in = c->stream[0], s_k = c->stream[1], s_out = c->stream[2];
   int k = 0;
   for (int64_t lo = 0; lo < n_sites; lo += chunk, ++k) {
@@ -995,7 +1000,7 @@ int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int6
     HIP_TRY(c, hipEventRecord(c->ev_in[s], s_in));
     // compute
     HIP_TRY(c, hipStreamWaitEvent(s_k, c->ev_in[s], 0));
-    const bool need_single = io.single || io.gpp;
+    const bool need_single = io.single || io.gpp || io.text;
     const bool need_status = io.status || called;
     bool fused = false;
     if (called && !io.post && !io.single) {
@@ -1012,6 +1017,8 @@ int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int6
         HIP_TRY(c, launch_phred_call(c->d_post[s], c->d_single[s], c->d_status[s], c->d_seq, N, n_seq, n, c->d_gpp[s],
                                      c->d_fpp[s], c->d_fgt[s], s_k));
     }
+    // the called outputs as text, while they are in HBM anyway: one record per (site, sample) pair
+    if (io.text) HIP_TRY(c, launch_text_call(c->d_gpp[s], c->d_fpp[s], c->d_fgt[s], n * n_seq, c->d_text[s], s_k));
     HIP_TRY(c, hipEventRecord(c->ev_done[s], s_k));
     // copy out
     HIP_TRY(c, hipStreamWaitEvent(s_out, c->ev_done[s], 0));
@@ -1020,6 +1027,8 @@ int run_chunks(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq, int6
       if (io.gpp) HIP_TRY(c, hipMemcpyAsync(io.gpp + lo * 3 * n_seq, c->d_gpp[s], n * cr, hipMemcpyDeviceToHost, s_out));
       if (io.fpp) HIP_TRY(c, hipMemcpyAsync(io.fpp + lo * 3 * n_seq, c->d_fpp[s], n * cr, hipMemcpyDeviceToHost, s_out));
       if (io.fgt) HIP_TRY(c, hipMemcpyAsync(io.fgt + lo * n_seq, c->d_fgt[s], n * n_seq, hipMemcpyDeviceToHost, s_out));
+      if (io.text)
+        HIP_TRY(c, hipMemcpyAsync(io.text + lo * n_seq * kTextStride, c->d_text[s], size_t(n) * n_seq * kTextStride, hipMemcpyDeviceToHost, s_out));
     }
     if (io.post) HIP_TRY(c, hipMemcpyAsync(io.post + lo * 3 * N, c->d_post[s], n * row, hipMemcpyDeviceToHost, s_out));
     if (io.single) HIP_TRY(c, hipMemcpyAsync(io.single + lo * 3 * N, c->d_single[s], n * row, hipMemcpyDeviceToHost, s_out));
@@ -1125,4 +1134,43 @@ extern "C" int famseq_bn_call_batch(famseq_ctx *c, int64_t n_sites, const double
   HostIO io;
   io.lk = lk; io.pl16 = pl16; io.flags = flags; io.gpp = gpp; io.fpp = fpp; io.fgt = fgt; io.status = status;
   return run_host(c, n_sites, io, n_seq);
+}
+
+static_assert(kTextStride == FAMSEQ_TEXT_STRIDE, "the header's record size is the text kernel's");
+
+extern "C" int famseq_bn_call_text_batch(famseq_ctx *c, int64_t n_sites, const double *lk, const uint16_t *pl16,
+                                         const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, char *text,
+                                         uint8_t *status) {
+  if (!c) return FAMSEQ_E_ARG;
+  if (n_sites < 0 || (n_sites > 0 && ((lk == nullptr) == (pl16 == nullptr))))
+    return fail(c, FAMSEQ_E_ARG, "exactly one of lk / pl16 must be given");
+  if (n_sites > 0 && !text) return fail(c, FAMSEQ_E_ARG, "text must be given");
+  if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
+  if (n_seq < 1) return fail(c, FAMSEQ_E_ARG, "n_seq must be >= 1");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int rc = set_sequenced(c, seq_members, n_seq);
+  if (rc != 0) return rc;
+  HostIO io;
+  io.lk = lk; io.pl16 = pl16; io.flags = flags; io.text = text; io.status = status;
+  return run_host(c, n_sites, io, n_seq);
+}
+
+extern "C" int famseq_format_probe(famseq_ctx *c, int64_t n, const double *values, char *out) {
+  if (!c) return FAMSEQ_E_ARG;
+  if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
+  if (n < 0 || (n > 0 && (!values || !out))) return fail(c, FAMSEQ_E_ARG, "bad probe arguments");
+  if (n == 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double *d_in = nullptr;
+  char *d_out = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&d_in), size_t(n) * sizeof(double)));
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_out), size_t(n) * 16);
+  if (e == hipSuccess) e = hipMemcpy(d_in, values, size_t(n) * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_g6_probe(d_in, n, d_out, c->stream[1]);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream[1]);
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, size_t(n) * 16, hipMemcpyDeviceToHost);
+  (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(c, FAMSEQ_E_HIP, std::string("famseq_format_probe: ") + hipGetErrorString(e));
+  return 0;
 }

@@ -108,7 +108,21 @@ struct TextBuf {
     q = famseq_fmt::g6(q, f[2]), *q++ = ':';
     n += size_t(q - p);
   }
+  // the same as the device wrote it (famseq_bn_call_text_batch): "a,b,c:d,e,f:0/1\t", FAMSEQ_TEXT_STRIDE bytes, the count in the last
+  void record(const char *r) {
+    char *p = room(FAMSEQ_TEXT_STRIDE);
+    std::memcpy(p, r, FAMSEQ_TEXT_STRIDE);
+    n += size_t((unsigned char)r[FAMSEQ_TEXT_STRIDE - 1]);
+  }
 };
+
+// Where the numbers become text: on the device (default — one more streaming kernel behind the call kernel, a record per
+// sample comes back: famseq_bn_call_text_batch) or on the host's cores (FAMSEQ_HOST_FORMAT=1: famseq_fmt::g6, sixty calls per
+// ten-member site, 0.74 of the 0.88 s loop per 3 M sites on 16 threads).  Both print the same bytes (csrc/g6_core.h).
+bool device_text() {
+  const char *e = std::getenv("FAMSEQ_HOST_FORMAT");
+  return !(e && std::atoi(e) != 0);
+}
 
 // pow(10, -|x|/10) for a PL/GL field (file.cpp:588-590).  Integer fields (the usual PL) go
 // through a table filled with the same libm pow call, so the value is identical.
@@ -699,19 +713,30 @@ struct PlBatch {
   uint16_t *pl = nullptr;
   double *gpp = nullptr, *fpp = nullptr;
   int8_t *fgt = nullptr;
-  bool alloc(size_t cap_, size_t k_) {
+  char *text = nullptr;  // as_text: the device's records instead of gpp / fpp / fgt
+  bool alloc(size_t cap_, size_t k_, bool as_text) {
     cap = cap_;
     k = k_;
     flags = static_cast<uint8_t *>(famseq_alloc_pinned(cap));
     status = static_cast<uint8_t *>(famseq_alloc_pinned(cap));
     pl = static_cast<uint16_t *>(famseq_alloc_pinned(cap * k * 6));
+    if (as_text) {
+      text = static_cast<char *>(famseq_alloc_pinned(cap * k * FAMSEQ_TEXT_STRIDE));
+      return flags && status && pl && text;
+    }
     gpp = static_cast<double *>(famseq_alloc_pinned(cap * k * 24));
     fpp = static_cast<double *>(famseq_alloc_pinned(cap * k * 24));
     fgt = static_cast<int8_t *>(famseq_alloc_pinned(cap * k));
     return flags && status && pl && gpp && fpp && fgt;
   }
   void release() {
-    for (void *q : {(void *)flags, (void *)status, (void *)pl, (void *)gpp, (void *)fpp, (void *)fgt}) famseq_free_pinned(q);
+    for (void *q : {(void *)flags, (void *)status, (void *)pl, (void *)gpp, (void *)fpp, (void *)fgt, (void *)text}) famseq_free_pinned(q);
+  }
+  // the GPU call of this batch's first n sites
+  int call(famseq_ctx *ctx, size_t n_sites, const double *lk, const int32_t *seq_members) {
+    if (text)
+      return famseq_bn_call_text_batch(ctx, (int64_t)n_sites, lk, lk ? nullptr : pl, flags, seq_members, (int32_t)k, text, status);
+    return famseq_bn_call_batch(ctx, (int64_t)n_sites, lk, lk ? nullptr : pl, flags, seq_members, (int32_t)k, gpp, fpp, fgt, status);
   }
 };
 
@@ -884,7 +909,8 @@ bool run_pl(const Options &o, const Ped &ped) {
     char *p = t.room(8);
     t.n += size_t(std::to_chars(p, p + 8, v).ptr - p);
   };
-  auto format_and_write = [&](size_t n, const uint16_t *pl, const uint8_t *status, const double *gpp, const double *fpp, const int8_t *fgt) {
+  auto format_and_write = [&](size_t n, const uint16_t *pl, const uint8_t *status, const double *gpp, const double *fpp, const int8_t *fgt,
+                              const char *rec) {
     const int parts = parallel_ranges(n, [&](size_t lo, size_t hi, int part) {
       TextBuf &line = text[part];
       line.n = 0;
@@ -904,6 +930,10 @@ bool run_pl(const Options &o, const Ped &ped) {
             continue;
           }
           line.ch(':');
+          if (rec) {
+            line.record(rec + (s * k + j) * FAMSEQ_TEXT_STRIDE);
+            continue;
+          }
           line.triples(&gpp[(s * k + j) * 3], &fpp[(s * k + j) * 3]);
           const int gt = fgt[s * k + j];
           line.put(gt == 0 ? "0/0\t" : (gt == 1 ? "0/1\t" : "1/1\t"), 4);
@@ -945,7 +975,7 @@ bool run_pl(const Options &o, const Ped &ped) {
     PlBatch bt[kBatches];
     bool ok = true;
     const double t_alloc0 = now_s();
-    for (PlBatch &b : bt) ok = b.alloc(cap, k) && ok;
+    for (PlBatch &b : bt) ok = b.alloc(cap, k, !o.bin_output && device_text()) && ok;
     const double t_alloc = now_s() - t_alloc0;
     if (!ok) std::cerr << "cannot allocate pinned host buffers" << std::endl;
     double t_read = 0, t_gpu = 0, t_write = 0;
@@ -998,7 +1028,7 @@ bool run_pl(const Options &o, const Ped &ped) {
           write_ok = g;
           written += b.n;
         } else {
-          format_and_write(b.n, b.pl, b.status, b.gpp, b.fpp, b.fgt);
+          format_and_write(b.n, b.pl, b.status, b.gpp, b.fpp, b.fgt, b.text);
           write_ok = write_ok && !fout.fail();
         }
         t_write += now_s() - t0;
@@ -1011,8 +1041,7 @@ bool run_pl(const Options &o, const Ped &ped) {
       PlBatch &b = bt[i];
       if (ok) {
         const double t0 = now_s();
-        const int rc = famseq_bn_call_batch(ctx, (int64_t)b.n, nullptr, b.pl, b.flags, seq_members.data(), (int32_t)k, b.gpp, b.fpp,
-                                            b.fgt, b.status);
+        const int rc = b.call(ctx, b.n, nullptr, seq_members.data());
         t_gpu += now_s() - t0;
         if (rc != 0) {
           std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx) << std::endl;
@@ -1074,7 +1103,7 @@ bool run_pl(const Options &o, const Ped &ped) {
       const char *r = raw.data() + s * rec;
       for (size_t j = 0; j < k; j++) std::memcpy(&pl[(s * k + j) * 3], r + 1 + 6 * seq_cols[j], 6);
     });
-    format_and_write(n, pl.data(), status.data(), gpp.data(), fpp.data(), fgt.data());
+    format_and_write(n, pl.data(), status.data(), gpp.data(), fpp.data(), fgt.data(), nullptr);
   }
   fout.close();
   return ok && !fout.fail();
@@ -1282,6 +1311,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
     });
   const PlTable pl;
   const size_t n_seq = seq_cols.size(), N3 = size_t(3) * ped.n();
+  const bool as_text = device_text();
 
   // What one parsing thread makes of its contiguous range of a block's lines, in input order.  The same thread
   // formats the same range once the block's sites are back from the GPU.
@@ -1444,7 +1474,6 @@ bool run_vcf(const Options &o, const Ped &ped) {
       const int i = to_flusher.take();
       if (i < 0) break;
       Slot &sl = slots[i];
-      const size_t k = n_seq;
       if (!ctx && ctx_future.valid()) {  // the first block: the context has been coming up meanwhile
         const double tw = now_s();
         ctx = ctx_future.get();
@@ -1456,7 +1485,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
         if (sl.io.cap < nl_) {
           sl.io.release();
           sl.io = PlBatch();
-          if (!sl.io.alloc(nl_, std::max<size_t>(n_seq, 1))) {
+          if (!sl.io.alloc(nl_, std::max<size_t>(n_seq, 1), as_text)) {
             std::cerr << "cannot allocate pinned host buffers" << std::endl;
             flush_ok = false;
           }
@@ -1468,8 +1497,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
       }
       const double t0 = now_s();
       if (sl.n_sites > 0 && flush_ok) {
-        const int rc = famseq_bn_call_batch(ctx, (int64_t)sl.n_sites, sl.packed ? nullptr : sl.lk.data(), sl.packed ? sl.io.pl : nullptr,
-                                            sl.io.flags, seq_members.data(), (int32_t)k, sl.io.gpp, sl.io.fpp, sl.io.fgt, sl.io.status);
+        const int rc = sl.io.call(ctx, sl.n_sites, sl.packed ? nullptr : sl.lk.data(), seq_members.data());
         if (rc != 0) {
           std::cerr << "famseq_bn_call_batch failed (" << rc << "): " << famseq_last_error(ctx) << std::endl;
           flush_ok = false;
@@ -1514,6 +1542,10 @@ bool run_vcf(const Options &o, const Ped &ped) {
                   } else {
                     out.put(it.raw + sm[j].off, sm[j].len);
                     out.ch(':');
+                  }
+                  if (sl.io.text) {
+                    out.record(sl.io.text + (s * k + j) * FAMSEQ_TEXT_STRIDE);
+                    continue;
                   }
                   out.triples(&sl.io.gpp[(s * k + j) * 3], &sl.io.fpp[(s * k + j) * 3]);
                   const int gt = sl.io.fgt[s * k + j];
@@ -1590,7 +1622,7 @@ bool run_vcf(const Options &o, const Ped &ped) {
     } else if (sl.io.cap < nl) {  // pinned, sized by the first block (a short file does not pay for 65,536 sites)
       sl.io.release();
       sl.io = PlBatch();
-      if (!sl.io.alloc(nl, std::max<size_t>(n_seq, 1))) {
+      if (!sl.io.alloc(nl, std::max<size_t>(n_seq, 1), as_text)) {
         std::cerr << "cannot allocate pinned host buffers" << std::endl;
         ok = false;
         to_driver.put(i);

@@ -19,5 +19,14 @@ hipError_t launch_phred_call(const double *d_post, const double *d_single, const
                              const int32_t *d_seq_members, int n_members, int n_seq, int64_t n_sites, double *d_gpp,
                              double *d_fpp, int8_t *d_fgt, hipStream_t stream);
 
+// GPP / FPP / FGT of n_items = n_sites * n_seq (site, sample) pairs -> the text the drivers print for each,
+// "g0,g1,g2:f0,f1,f2:0/1\t", one kTextStride-byte record per pair: characters from byte 0, their number in the last byte
+// (file.cpp:696-745: `ostream << double`, i.e. printf's %g; csrc/g6_core.h).  d_text must be 16-byte aligned.
+constexpr int kTextStride = 80;
+hipError_t launch_text_call(const double *d_gpp, const double *d_fpp, const int8_t *d_fgt, int64_t n_items, char *d_text,
+                            hipStream_t stream);
+// diagnostic / test aid: n doubles -> n 16-byte records (characters of g6_phred from byte 0, their number in byte 15)
+hipError_t launch_g6_probe(const double *d_in, int64_t n, char *d_out, hipStream_t stream);
+
 }  // namespace famseq
 #endif

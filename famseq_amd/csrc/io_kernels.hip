@@ -19,6 +19,7 @@
 // these two remain for the compiled-in team kernel and the lanes-per-site mode.
 #include <hip/hip_runtime.h>
 
+#include "g6_core.h"
 #include "io_kernels.h"
 
 namespace famseq {
@@ -128,6 +129,72 @@ __global__ __launch_bounds__(256) void stream_probe_kernel(const v2d_ *__restric
   }
 }
 
+// text_call: one lane per (site, sample) pair.  The lane writes its record's characters one byte at a time into its LDS
+// record (84-byte stride: 21 words, odd, so the 64 lanes of a wave writing "their" byte k hit 64 different banks); the
+// workgroup then copies the tile's records out 16 bytes per lane, contiguous across the wave.  What the host would do
+// with the six doubles — six %g conversions, 60 per ten-member site, the slowest stage of `FamSeq vcf` — is ~1,000
+// integer instructions per pair here, 0.3 ms per million ten-member sites, and the host is left with one memcpy per pair.
+constexpr int kRecWords = 21;  // LDS stride of a record in 4-byte words (kTextStride / 4 = 20 are copied out)
+static_assert(kTextStride == 80, "the copy-out below moves five 16-byte pieces per record");
+
+typedef unsigned fs_v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void text_call_kernel(const double *__restrict__ gpp, const double *__restrict__ fpp,
+                                                        const int8_t *__restrict__ fgt, long n_items, fs_v4u *__restrict__ text) {
+  __shared__ uint32_t s_rec[256 * kRecWords];
+  const long tiles = (n_items + 255) / 256;
+  for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const long item0 = t * 256;
+    const int ni = n_items - item0 < 256 ? (int)(n_items - item0) : 256;
+    const int tid = threadIdx.x;
+    if (tid < ni) {
+      const long i = item0 + tid;
+      const double g0 = gpp[i * 3], g1 = gpp[i * 3 + 1], g2 = gpp[i * 3 + 2];
+      const double f0 = fpp[i * 3], f1 = fpp[i * 3 + 1], f2 = fpp[i * 3 + 2];
+      const int gt = fgt[i];
+      uint32_t *w = s_rec + tid * kRecWords;
+#pragma unroll
+      for (int k = 0; k < kTextStride / 4; ++k) w[k] = 0;
+      unsigned char *rec = reinterpret_cast<unsigned char *>(w);
+      int pos = 0;
+      pos += famseq_g6::g6_phred(rec + pos, g0), rec[pos++] = ',';
+      pos += famseq_g6::g6_phred(rec + pos, g1), rec[pos++] = ',';
+      pos += famseq_g6::g6_phred(rec + pos, g2), rec[pos++] = ':';
+      pos += famseq_g6::g6_phred(rec + pos, f0), rec[pos++] = ',';
+      pos += famseq_g6::g6_phred(rec + pos, f1), rec[pos++] = ',';
+      pos += famseq_g6::g6_phred(rec + pos, f2), rec[pos++] = ':';
+      // get_postRlt's 0 / 1 / 2 as the drivers print it (file.cpp:733-745): "0/0", "0/1", anything else "1/1"
+      rec[pos] = gt == 0 || gt == 1 ? '0' : '1';
+      rec[pos + 1] = '/';
+      rec[pos + 2] = gt == 0 ? '0' : '1';
+      rec[pos + 3] = '\t';
+      rec[kTextStride - 1] = (unsigned char)(pos + 4);  // <= 6 * 11 + 6 + 4 = 76
+    }
+    __syncthreads();
+    fs_v4u *out = text + item0 * (kTextStride / 16);
+    for (int q = tid; q < ni * (kTextStride / 16); q += 256) {
+      const int r = q / 5, p = q - r * 5;
+      const uint32_t *w = s_rec + r * kRecWords + p * 4;
+      fs_v4u v;
+      v.x = w[0], v.y = w[1], v.z = w[2], v.w = w[3];
+      __builtin_nontemporal_store(v, out + q);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void g6_probe_kernel(const double *__restrict__ in, long n, fs_v4u *__restrict__ out) {
+  __shared__ uint32_t s_rec[256 * 5];  // 20-byte stride: odd in words
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    uint32_t *w = s_rec + threadIdx.x * 5;
+    w[0] = w[1] = w[2] = w[3] = 0;
+    unsigned char *c = reinterpret_cast<unsigned char *>(w);
+    c[15] = (unsigned char)famseq_g6::g6_phred(c, in[i]);
+    fs_v4u v;
+    v.x = w[0], v.y = w[1], v.z = w[2], v.w = w[3];
+    out[i] = v;
+  }
+}
+
 int grid_for(long n_sites) {
   const long tiles = (n_sites + kTileSites - 1) / kTileSites;
   return (int)(tiles < 1 ? 1 : (tiles > 16384 ? 16384 : tiles));
@@ -158,6 +225,24 @@ hipError_t launch_phred_call(const double *d_post, const double *d_single, const
   if (n_seq > kMaxIoMembers || n_members > kMaxIoMembers) return hipErrorInvalidValue;  // div_small's range
   hipLaunchKernelGGL(phred_call_kernel, dim3(grid_for(n_sites)), dim3(256), 0, stream, d_post, d_single,
                      d_status, d_seq_members, n_members, n_seq, (long)n_sites, d_gpp, d_fpp, d_fgt);
+  return hipGetLastError();
+}
+
+hipError_t launch_text_call(const double *d_gpp, const double *d_fpp, const int8_t *d_fgt, int64_t n_items, char *d_text,
+                            hipStream_t stream) {
+  if (n_items <= 0) return hipSuccess;
+  if (reinterpret_cast<uintptr_t>(d_text) & 15) return hipErrorInvalidValue;
+  const long tiles = (n_items + 255) / 256;
+  hipLaunchKernelGGL(text_call_kernel, dim3((unsigned)(tiles > 16384 ? 16384 : tiles)), dim3(256), 0, stream, d_gpp, d_fpp, d_fgt,
+                     (long)n_items, reinterpret_cast<fs_v4u *>(d_text));
+  return hipGetLastError();
+}
+
+hipError_t launch_g6_probe(const double *d_in, int64_t n, char *d_out, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(g6_probe_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, stream, d_in, (long)n,
+                     reinterpret_cast<fs_v4u *>(d_out));
   return hipGetLastError();
 }
 

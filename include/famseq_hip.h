@@ -224,6 +224,26 @@ int famseq_bn_call_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, con
                          const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, double *gpp, double *fpp,
                          int8_t *fgt, uint8_t *status);
 
+/* The same call with the outputs as TEXT (SURVEY.md 8(f) rows N1 + N2): what the reference's drivers append to every
+ * sample column of an output line (file.cpp:696-745) — the GPP triple, the FPP triple and the called genotype,
+ * "g0,g1,g2:f0,f1,f2:0/1\t", every number as C++ `ostream << double` prints it (printf's %g: six significant digits of the
+ * exact binary value, round-half-even) — formatted on the device by one more streaming kernel over the called outputs
+ * while they are in HBM (csrc/io_kernels.hip text_call_kernel; csrc/g6_core.h is the digit code it shares with the host
+ * formatter).  The sixty %g conversions per ten-member site were the slowest stage of the command line (0.74 of its 0.88 s
+ * loop per 3 M sites on 16 host threads); with this entry the host copies one record per sample.
+ *   text [n_sites][n_seq][FAMSEQ_TEXT_STRIDE]  one record per (site, sequenced sample) in VCF column order: the characters
+ *        from byte 0, their count (<= 76) in byte FAMSEQ_TEXT_STRIDE - 1, zeros between.  Records of a site whose
+ *        status has bit 0 or 1 set hold no number to print (the drivers write ":NA:NA:NA" there, file.cpp:607-620).
+ * Other arguments, chunking and kernels as famseq_bn_call_batch; 80 n_seq + 1 bytes per site come back. */
+#define FAMSEQ_TEXT_STRIDE 80
+int famseq_bn_call_text_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, const uint16_t *pl16,
+                              const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, char *text, uint8_t *status);
+
+/* Diagnostic / test aid: the device formatter alone.  values[n] (host) -> out[n][16] (host): the characters of each
+ * value as the text kernel prints a GPP / FPP number from byte 0, their count in byte 15; "nan" for anything outside
+ * the formatter's domain, 0 and [1e-16, 999999.5). */
+int famseq_format_probe(famseq_ctx *ctx, int64_t n, const double *values, char *out);
+
 /* Diagnostic for measurement (bench.py): runs the posterior kernels' traffic shape — read one fp64 array of
  * n_doubles, write two — as a bare elementwise kernel on `stream` and returns without synchronising.  What a
  * device's memory system sustains for that shape differs between MI355X devices by 10-20 %; timing this next to

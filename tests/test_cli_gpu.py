@@ -304,3 +304,30 @@ def test_sites_moved_together_for_large_pedigrees(batch, tmp_path):
         p = subprocess.run([CLI, "vcf"] + args + ["-output", str(out)], capture_output=True, text=True, env=env)
         assert p.returncode == 0, p.stdout + p.stderr
         assert assert_same_output(out, ref) > 0
+
+
+@pytest.mark.parametrize("vcf,ped,extra,batch", [("test_full.vcf.gz", "fam01.ped", ["-a"], None), ("test_full.vcf.gz", "fam04.ped", [], "1000"),
+                                                 ("probe.vcf", "probe.ped", ["-a"], "3"), ("test_subset.vcf", "fam06.ped", ["-v"], None)])
+def test_device_text_is_the_host_formatter_text(vcf, ped, extra, batch, tmp_path):
+    """The numbers are turned into text on the device (famseq_bn_call_text_batch, the default) or by the host formatter
+    (FAMSEQ_HOST_FORMAT=1: csrc/host/fmt_g6.h, itself checked against printf): the same bytes, failed sites, missing samples
+    and echoed lines included."""
+    import gzip
+    import shutil
+
+    src = TD + "/" + vcf
+    if vcf.endswith(".gz"):
+        src = str(tmp_path / "in.vcf")
+        with gzip.open(TD + "/" + vcf, "rb") as f, open(src, "wb") as g:
+            shutil.copyfileobj(f, g)
+    outs = []
+    for host in ("0", "1"):
+        env = dict(os.environ, FAMSEQ_HOST_FORMAT=host)
+        if batch:
+            env["FAMSEQ_BATCH"] = batch
+        out = tmp_path / ("o%s.vcf" % host)
+        p = subprocess.run([CLI, "vcf", "-vcfFile", src, "-pedFile", TD + "/" + ped, "-output", str(out)] + extra, capture_output=True,
+                           text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and outs[0].count(b":GPP:FPP:FGT") >= 10

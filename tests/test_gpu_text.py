@@ -1,0 +1,102 @@
+"""Device-side text (famseq_bn_call_text_batch, rows N1 + N2): the characters the reference's drivers append to every sample
+column — GPP triple, FPP triple, called genotype (file.cpp:696-745) — formatted on the GPU.  Checked against Python's
+'%g' (correctly rounded, i.e. what printf and `ostream << double` print) of the numbers famseq_bn_call_batch returns, on
+every fixture through three engines, and the formatter alone on ties, decade edges and random Phred-shaped values."""
+import math
+
+import numpy as np
+import pytest
+
+import famseq_amd as fs
+from _cases import load_cases
+
+pytestmark = pytest.mark.gpu
+CASES = load_cases()
+ENGINES = [("lane, fused", dict(enum_impl=1)), ("sum-product, fused", dict(engine=fs.ENGINE_ELIM)),
+           ("team + separate stages", dict(enum_impl=0))]
+
+
+def expected_record(g, f, gt):
+    return ("%g,%g,%g:%g,%g,%g:%s\t" % (g[0], g[1], g[2], f[0], f[1], f[2], {0: "0/0", 1: "0/1"}.get(int(gt), "1/1"))).encode()
+
+
+@pytest.fixture(scope="module")
+def any_ctx():
+    c = next(x for x in CASES if x.name == "bn_synth:quad")
+    ctx = fs.Context(fs.make_model(c.pedigree(), **c.consts))
+    yield ctx
+    ctx.close()
+
+
+def test_device_formatter_equals_printf(any_ctx):
+    rng = np.random.RandomState(7)
+    vals = [0.0, 1.0, 10.0, 99999.0, 100000.0, 999999.0, 999999.4, 524288.0, 745679.5, 1e-4, 9.99999e-5, 9.999995e-5, 0.000123456,
+            1e-5, 1e-16, 1.00000001e-16, 4.8216e-16, 0.5, 1.5, 2.5, 123456.5, 123457.5, 12345.65, 2.83856e-06, 61.8469, 220.877,
+            3239.9999, 0.1, 0.2, 0.3, 1.0 / 3, 2.0 / 3]
+    # exact ties at every digit position, one ulp either side of powers of ten and of six-digit decimals
+    for _ in range(20000):
+        t = float(rng.randint(100000, 1000000)) + 0.5
+        vals.append(t)
+        vals.extend(math.ldexp(t, -j) for j in range(1, 41, 3))
+    for x in range(-16, 6):
+        p = 10.0 ** x
+        vals.extend([p, np.nextafter(p, 0), np.nextafter(p, 1e9)])
+        for _ in range(300):
+            d = float(rng.randint(100000, 1000000)) * 10.0 ** (x - 5)
+            h = (float(rng.randint(100000, 1000000)) + 0.5) * 10.0 ** (x - 5)
+            vals.extend([d, np.nextafter(d, 0), np.nextafter(d, 1e9), h, np.nextafter(h, 0), np.nextafter(h, 1e9)])
+    vals = np.array([v for v in vals if v == 0 or 1e-16 <= v < 999999.5])
+    # log-uniform over the whole range, and Phred values of random probabilities (next to 1, uniform, tiny)
+    u = rng.random_sample(400000)
+    vals = np.concatenate([vals, 10.0 ** (-16 + 21.9 * u), np.abs(-10 * np.log10(rng.random_sample(400000))),
+                           np.abs(-10 * np.log10(1 - np.ldexp(rng.random_sample(200000), -rng.randint(0, 53, 200000)))),
+                           np.abs(-10 * np.log10(10.0 ** (-300 * rng.random_sample(200000))))])
+    vals = vals[(vals == 0) | ((vals >= 1e-16) & (vals < 999999.5))]
+    got = any_ctx.g6_probe(vals)
+    bad = [(v, g) for v, g in zip(vals, got) if g != ("%g" % v).encode()]
+    assert not bad, bad[:10]
+    assert any_ctx.g6_probe([float("nan"), -1.0, 1e7, 1e-20]) == [b"nan"] * 4  # outside the domain: never produced for a computed site
+
+
+@pytest.mark.parametrize("label,opts", ENGINES, ids=[e[0] for e in ENGINES])
+def test_text_records_on_every_fixture(label, opts):
+    n = 0
+    for c in CASES:
+        if not c.name.startswith("bn_"):
+            continue
+        ctx = fs.Context(fs.make_model(c.pedigree(), **c.consts), **opts)
+        seq = np.nonzero(c.sequenced)[0][::-1].copy()  # a column order different from PED order
+        gpp, fpp, fgt, st = ctx.bn_call_batch(seq, lk=c.lk, flags=c.flags)
+        text, st2 = ctx.bn_call_text_batch(seq, lk=c.lk, flags=c.flags)
+        ctx.close()
+        assert np.array_equal(st, st2), c.name
+        for s in np.nonzero((st & 3) == 0)[0]:
+            for j in range(len(seq)):
+                rec = text[s, j]
+                assert bytes(rec[:rec[-1]]) == expected_record(gpp[s, j], fpp[s, j], fgt[s, j]), (c.name, s, j)
+                assert not rec[rec[-1]:-1].any()
+                n += 1
+    assert n > 1000
+
+
+def test_text_from_packed_pls_at_size():
+    """A batch of several chunks and tiles (the text kernel walks 256 pairs per tile; the host pipeline cuts chunks)."""
+    ped = fs.synthetic_pedigree("ped10")
+    s = 70001
+    mo, fa = ped.relations()
+    pl, known, _ = fs.synth.gen_sites(mo, fa, s, seed=fs.synth.SEED_BASE + 2)
+    seq = np.arange(ped.n, dtype=np.int32)
+    ctx = fs.Context(fs.make_model(ped), engine=fs.ENGINE_ELIM, chunk_sites=16384)
+    gpp, fpp, fgt, st = ctx.bn_call_batch(seq, pl16=pl.astype(np.uint16), flags=known.astype(np.uint8))
+    text, st2 = ctx.bn_call_text_batch(seq, pl16=pl.astype(np.uint16), flags=known.astype(np.uint8))
+    ctx.close()
+    assert np.array_equal(st, st2) and not (st & 3).any()
+    for i in list(range(0, s, 977)) + [16383, 16384, s - 1]:
+        for j in range(ped.n):
+            rec = text[i, j]
+            assert bytes(rec[:rec[-1]]) == expected_record(gpp[i, j], fpp[i, j], fgt[i, j]), (i, j)
+    # every record well-formed: a length, a tab at its end, zeros behind it
+    ln = text[:, :, -1].astype(int)
+    assert ln.min() >= 16 and ln.max() <= 76
+    flat = text.reshape(-1, fs.TEXT_STRIDE)
+    assert np.all(flat[np.arange(len(flat)), ln.ravel() - 1] == ord("\t"))

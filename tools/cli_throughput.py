@@ -22,13 +22,13 @@ pedigree.write_ped(ped, pedf)
 cli = os.path.join(ROOT, "bin", "FamSeq")
 
 
-def run(a, label):
+def run(a, label, **env):
     ts = []
     for _ in range(2):
         out = a[a.index("-output") + 1]
         if os.path.exists(out):  # (overwriting a 1.5 GB file that sits in the page cache costs the second run 0.4 s of truncation:
             os.unlink(out)       # round 2's figures carried that; the file is removed outside the timed region now)
-        t0 = time.time(); subprocess.check_call([cli] + a, stdout=subprocess.DEVNULL, env=dict(os.environ, FAMSEQ_TIMING="1")); ts.append(time.time() - t0)
+        t0 = time.time(); subprocess.check_call([cli] + a, stdout=subprocess.DEVNULL, env=dict(os.environ, FAMSEQ_TIMING="1", **env)); ts.append(time.time() - t0)
     print("%-14s %.2f s  %.2f M sites/s   [first run %.2f s]" % (label, ts[1], n / ts[1] / 1e6, ts[0]), flush=True)
 
 
@@ -45,8 +45,14 @@ else:
     t0 = time.time(); synth.write_vcf(vcf, ped.names, pl, known, geno)
     print("wrote %d-site VCF (%.0f MB) in %.1f s" % (n, os.path.getsize(vcf) / 1e6, time.time() - t0), flush=True)
     run(["vcf", "-vcfFile", vcf, "-pedFile", pedf, "-output", os.path.join(d, "o.vcf")], "FamSeq vcf")
+    run(["vcf", "-vcfFile", vcf, "-pedFile", pedf, "-output", os.path.join(d, "oh.vcf")], "vcf, host fmt", FAMSEQ_HOST_FORMAT="1")
+    same = subprocess.call(["cmp", "-s", os.path.join(d, "o.vcf"), os.path.join(d, "oh.vcf")]) == 0
+    print("device-formatted and host-formatted output identical:", same, flush=True)
+    os.unlink(os.path.join(d, "oh.vcf"))
     run(["pack", "-vcfFile", vcf, "-pedFile", pedf, "-output", fspl], "FamSeq pack")
 run(["PL", "-plFile", fspl, "-pedFile", pedf, "-output", os.path.join(d, "o.txt")], "FamSeq PL")
+run(["PL", "-plFile", fspl, "-pedFile", pedf, "-output", os.path.join(d, "oh.txt")], "PL, host fmt", FAMSEQ_HOST_FORMAT="1")
+os.unlink(os.path.join(d, "oh.txt"))
 run(["PL", "-plFile", fspl, "-pedFile", pedf, "-output", os.path.join(d, "o.fspo"), "-binOutput"], "PL -binOutput")
 run(["PL", "-plFile", fspl, "-pedFile", pedf, "-output", os.path.join(d, "o2.fspo"), "-binOutput", "-method", "2"], "PL -bin -m 2")
 print("packed results: %.1f MB, packed input: %.1f MB" % (os.path.getsize(os.path.join(d, "o.fspo")) / 1e6, os.path.getsize(fspl) / 1e6))
