@@ -38,7 +38,9 @@ struct CallIO {  // = struct fs_call_args of the generated source (elim_codegen.
   int8_t *fgt = nullptr;
   int32_t n_seq = 0;
   uint32_t magic_w = 0, magic_n = 0;
+  unsigned long long *phase_clk = nullptr;  // FAMSEQ_PHASE_CLOCK (measuring aid): cycles per phase of the call-path kernel, summed over waves
 };
+constexpr int kPhases = 8;
 
 struct famseq_ctx {
   Model model;
@@ -104,6 +106,7 @@ struct famseq_ctx {
   double *d_lut = nullptr;
   int32_t *d_seq = nullptr, *d_col = nullptr;
   CallIO *d_call[kSlots] = {};  // the generated kernels' call-path arguments, one per slot
+  unsigned long long *d_phase = nullptr;  // FAMSEQ_PHASE_CLOCK: kPhases counters
   std::vector<int32_t> seq_members;
   std::string tune_report;  // what famseq_set_option "tune" measured (famseq_plan_json "tune")
   std::string err, json;
@@ -393,17 +396,16 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
     const Model &mdl = c->model;
     std::string src;
     if (elim) {
-      const bool regs = std::getenv("FAMSEQ_ELIM_CALL_REGS") != nullptr;  // tuning aid: the registers-first family for the call path too
-      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, regs ? kElimVariants : kElimCallVariants, nullptr,
-                             regs ? 4 : elim_first_variant(mdl, true));
+      src = jit_pick_variant([&mdl](int v) { return elim_source(mdl, v, true); }, kElimCallVariants, nullptr, elim_first_variant(mdl, true));
     } else {
       // the same block size as the plain lane kernel runs with (variants 0-1 / 2-3: kEnumVariants), so that a batch
       // gives the same bits whether it goes through the fused kernel or through the separate stages
       if (!load_lane(c, 0)) throw std::runtime_error("the plain lane kernel is unavailable: " + c->lane_error);
       const int base = c->lane_variant >= 0 ? (c->lane_variant & ~1) : 0;
       int pick = 0;
-      src = jit_pick_variant([&mdl, base](int v) { return enumgen_source(mdl, base + v, 0, true); }, 2, &pick);
-      c->lane_call_variant = base + pick;
+      // v & 1: the single posterior fenced member by member; v & 2: the leaner stage-out (see kElimCallVariants)
+      src = jit_pick_variant([&mdl, base](int v) { return enumgen_source(mdl, base + (v & 1), 0, true, !(v & 2)); }, 4, &pick);
+      c->lane_call_variant = base + (pick & 1);
       c->lane_reads_rows = enumgen_reads_global_rows(mdl, c->lane_call_variant) ? 1 : 0;
     }
     if (c->device < 0) {
@@ -966,6 +968,11 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
       // e / d for e < 2^16, d <= 60 as the high word of e * (2^32 / d + 1): exact (io_kernels.hip)
       cio.magic_w = 0xFFFFFFFFu / uint32_t(3 * n_seq) + 1;
       cio.magic_n = n_seq > 1 ? 0xFFFFFFFFu / uint32_t(n_seq) + 1 : 0;  // one column: the kernel divides by 1 itself
+      if (std::getenv("FAMSEQ_PHASE_CLOCK")) {
+        if (!c->d_phase) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_phase), kPhases * sizeof(unsigned long long)));
+        if (s == 0) HIP_TRY(c, hipMemset(c->d_phase, 0, kPhases * sizeof(unsigned long long)));
+        cio.phase_clk = c->d_phase;
+      }
       HIP_TRY(c, hipMemcpy(c->d_call[s], &cio, sizeof cio, hipMemcpyHostToDevice));
     }
   }
@@ -975,6 +982,15 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
   for (int s = 0; s < famseq_ctx::kStages; ++s) {
     const hipError_t e = hipStreamSynchronize(c->stream[s]);
     if (e != hipSuccess && rc == 0) return fail(c, FAMSEQ_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+  }
+  if (called && c->d_phase && rc == 0) {  // measuring aid: where the call-path kernel's waves spend their cycles
+    unsigned long long ph[kPhases];
+    HIP_TRY(c, hipMemcpy(ph, c->d_phase, sizeof ph, hipMemcpyDeviceToHost));
+    unsigned long long tot = 0;
+    for (int i = 0; i < kPhases; ++i) tot += ph[i];
+    std::fprintf(stderr, "famseq phase clock (wave cycles, %lld sites):", (long long)n_sites);
+    for (int i = 0; i < kPhases; ++i) std::fprintf(stderr, " [%d] %.1f%%", i, tot ? 100.0 * double(ph[i]) / double(tot) : 0.0);
+    std::fprintf(stderr, "  total %llu\n", tot);
   }
   return rc;
 }

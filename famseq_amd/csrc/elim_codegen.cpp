@@ -482,13 +482,28 @@ struct fs_call_args {
   else { for (int it_ = tid; it_ < ns * NMEM; it_ += BT) PL_ITEM(it_) } }
 // The lane's row holds probabilities (single or BN posterior, NaN where the site failed): turn it in place
 // into what is printed, fabs(-10 log10 p), and note the arg-max genotype of every member (strict '<' from
-// -1: ties to the lower genotype, NaN rows give -1).  3 N independent logarithms per lane: plenty of ILP.
-#define ROW_TO_CALL() { _Pragma("unroll") for (int p_ = 0; p_ < NMEM; ++p_) { \
-    const double d0_ = row[3 * p_], d1_ = row[3 * p_ + 1], d2_ = row[3 * p_ + 2]; \
-    signed char pk_ = -1; double bs_ = -1; \
-    if (bs_ < d0_) { bs_ = d0_; pk_ = 0; } if (bs_ < d1_) { bs_ = d1_; pk_ = 1; } if (bs_ < d2_) { bs_ = d2_; pk_ = 2; } \
-    s_fgt[tid * NMEM + p_] = pk_; \
-    row[3 * p_] = fs_phred(d0_, s_lt); row[3 * p_ + 1] = fs_phred(d1_, s_lt); row[3 * p_ + 2] = fs_phred(d2_, s_lt); } }
+// -1: ties to the lower genotype, NaN rows give -1).  3 N independent logarithms per lane — independent for the
+// scheduler only inside one basic block: with fs_phred's own branch per logarithm (the special values) each one was a
+// block of its own, table read -> wait -> nine dependent FMAs, thirty times in a row.  Two members at a time, the
+// six logarithms branch-free and ONE branch behind them for the rare row that holds a zero or a NaN.
+#define ARGMAX3(a0_, a1_, a2_, slot_) { signed char pk_ = -1; double bs_ = -1; \
+    if (bs_ < a0_) { bs_ = a0_; pk_ = 0; } if (bs_ < a1_) { bs_ = a1_; pk_ = 1; } if (bs_ < a2_) { bs_ = a2_; pk_ = 2; } \
+    s_fgt[tid * NMEM + (slot_)] = pk_; }
+#define ROW_TO_CALL() { _Pragma("unroll") for (int p_ = 0; p_ + 1 < (FS_PHRED_GROUP == 2 ? NMEM : 0); p_ += 2) { \
+    const double d0_ = row[3 * p_], d1_ = row[3 * p_ + 1], d2_ = row[3 * p_ + 2], d3_ = row[3 * p_ + 3], d4_ = row[3 * p_ + 4], d5_ = row[3 * p_ + 5]; \
+    ARGMAX3(d0_, d1_, d2_, p_) ARGMAX3(d3_, d4_, d5_, p_ + 1) \
+    double q0_ = fs_phred_fast(d0_, s_lt), q1_ = fs_phred_fast(d1_, s_lt), q2_ = fs_phred_fast(d2_, s_lt); \
+    double q3_ = fs_phred_fast(d3_, s_lt), q4_ = fs_phred_fast(d4_, s_lt), q5_ = fs_phred_fast(d5_, s_lt); \
+    if (!(FS_IS_POS_FINITE(d0_) & FS_IS_POS_FINITE(d1_) & FS_IS_POS_FINITE(d2_) & FS_IS_POS_FINITE(d3_) & FS_IS_POS_FINITE(d4_) & FS_IS_POS_FINITE(d5_))) { \
+      FS_KEEP_BRANCH(); q0_ = fs_phred_fix(d0_, q0_); q1_ = fs_phred_fix(d1_, q1_); q2_ = fs_phred_fix(d2_, q2_); \
+      q3_ = fs_phred_fix(d3_, q3_); q4_ = fs_phred_fix(d4_, q4_); q5_ = fs_phred_fix(d5_, q5_); } \
+    row[3 * p_] = q0_; row[3 * p_ + 1] = q1_; row[3 * p_ + 2] = q2_; row[3 * p_ + 3] = q3_; row[3 * p_ + 4] = q4_; row[3 * p_ + 5] = q5_; } \
+  _Pragma("unroll") for (int p_ = (FS_PHRED_GROUP == 2 ? (NMEM & ~1) : 0); p_ < NMEM; ++p_) { const double d0_ = row[3 * p_], d1_ = row[3 * p_ + 1], d2_ = row[3 * p_ + 2]; \
+    ARGMAX3(d0_, d1_, d2_, p_) \
+    double q0_ = fs_phred_fast(d0_, s_lt), q1_ = fs_phred_fast(d1_, s_lt), q2_ = fs_phred_fast(d2_, s_lt); \
+    if (!(FS_IS_POS_FINITE(d0_) & FS_IS_POS_FINITE(d1_) & FS_IS_POS_FINITE(d2_))) { \
+      FS_KEEP_BRANCH(); q0_ = fs_phred_fix(d0_, q0_); q1_ = fs_phred_fix(d1_, q1_); q2_ = fs_phred_fix(d2_, q2_); } \
+    row[3 * p_] = q0_; row[3 * p_ + 1] = q1_; row[3 * p_ + 2] = q2_; } }
 // rows -> [site][VCF column][genotype], coalesced; FGT likewise from the byte table
 #define CALL_ELEM(e_) { const int s_ = (int)FS_UMULHI((unsigned)(e_), mg_), r_ = (e_) - s_ * w_, k_ = (r_ * 171) >> 9; \
     __builtin_nontemporal_store(s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)], g_ + (e_)); }
@@ -497,15 +512,83 @@ struct fs_call_args {
     const int w1_ = r_ + 1 == w_, s1_ = s_ + w1_, r1_ = w1_ ? 0 : r_ + 1, k1_ = (r1_ * 171) >> 9; \
     fs_v2d v_; v_.x = s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)]; v_.y = s_io[s1_ * ROW + 3 * s_seq[k1_] + (r1_ - 3 * k1_)]; \
     __builtin_nontemporal_store(v_, (FS_GLOBAL fs_v2d *)(g_ + e_)); }
+// (NSEQ_CT: the pedigree's number of sequenced members, what n_seq is unless the caller names another set of columns.  With the
+// row width a constant the walk over a whole chunk has no bound to test per step — each test was a branch, each branch a basic
+// block of its own: index read -> wait -> value read -> wait -> store, fifteen times in a row — and its loads go out together.)
+// FS_CT_OUT = 2: the walk in groups of four steps, fenced one from the next — four steps' loads in flight together instead of all
+// fifteen: a dozen registers instead of sixty (at the 256-register cap of two waves per SIMD all fifteen spill)
+// The walks' indices depend on the lane only.  Left alone, hipcc computes them once, before the chunk loop — free while registers
+// are (small pedigrees: 0.067 against 0.088 ms per 1 M trios), sixty spilled registers at the 256 cap otherwise.  FS_OPAQUE_LANE
+// (from seven members on; the enumeration's form from five) makes the lane id opaque at each walk, so that they are formed again per chunk.
+#define FS_HIDE_LANE(t_) if (FS_OPAQUE_LANE) asm volatile("" : "+v"(t_))
+#define FS_OUT_FENCE(j_) if (FS_CT_OUT == 2 && ((j_) & 3) == 3) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define CALL_PAIR_CT(p2_) { const int e_ = 2 * (p2_), s_ = e_ / (3 * NSEQ_CT), r_ = e_ - s_ * (3 * NSEQ_CT), k_ = (r_ * 171) >> 9; \
+    const int w1_ = r_ + 1 == 3 * NSEQ_CT, s1_ = s_ + w1_, r1_ = w1_ ? 0 : r_ + 1, k1_ = (r1_ * 171) >> 9; \
+    fs_v2d v_; v_.x = s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)]; v_.y = s_io[s1_ * ROW + 3 * s_seq[k1_] + (r1_ - 3 * k1_)]; \
+    __builtin_nontemporal_store(v_, (FS_GLOBAL fs_v2d *)(g_ + e_)); }
 #define STAGE_OUT_CALL(Gp) { const int w_ = 3 * call_g->n_seq; const unsigned mg_ = call_g->magic_w; FS_GLOBAL double *g_ = (Gp) + site0 * w_; \
-  if (whole && (BT & 1) == 0 && ((unsigned long)g_ & 15) == 0) { const int half_ = BT / 2 * w_; \
+  if (FS_CT_OUT && whole && (BT & 1) == 0 && ((unsigned long)g_ & 15) == 0 && w_ == 3 * NSEQ_CT) { \
+    int t_ = tid; FS_HIDE_LANE(t_);  /* opaque: the walk's indices depend on the lane only, and hipcc would keep all of them in registers (spilled) across the chunk loop */ \
+    _Pragma("unroll") for (int j_ = 0; j_ < (3 * NSEQ_CT) / 2; ++j_) { CALL_PAIR_CT(t_ + j_ * BT) FS_OUT_FENCE(j_) } \
+    if ((3 * NSEQ_CT) & 1) { if (t_ < BT / 2) CALL_PAIR_CT(t_ + (3 * NSEQ_CT) / 2 * BT) } } \
+  else if (whole && (BT & 1) == 0 && ((unsigned long)g_ & 15) == 0) { const int half_ = BT / 2 * w_; \
     _Pragma("unroll") for (int j_ = 0; j_ < (3 * NMEM + 1) / 2; ++j_) if (tid + j_ * BT < half_) CALL_PAIR(tid + j_ * BT) } \
   else if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < 3 * NMEM; ++j_) if (j_ < w_) CALL_ELEM(tid + j_ * BT) } \
   else { for (int e = tid; e < ns * w_; e += BT) CALL_ELEM(e) } }
 #define STAGE_FGT(Gp) { const int n_seq = call_g->n_seq; const unsigned mg_ = call_g->magic_n; FS_GLOBAL signed char *g_ = (Gp) + site0 * n_seq; \
-  for (int it_ = tid; it_ < ns * n_seq; it_ += BT) { const int s_ = mg_ ? (int)FS_UMULHI((unsigned)it_, mg_) : it_, k_ = it_ - s_ * n_seq; \
+  if (FS_CT_OUT && whole && n_seq == NSEQ_CT) { int t_ = tid; FS_HIDE_LANE(t_); \
+    _Pragma("unroll") for (int j_ = 0; j_ < NSEQ_CT; ++j_) { const int it_ = t_ + j_ * BT, s_ = it_ / NSEQ_CT, k_ = it_ - s_ * NSEQ_CT; \
+    g_[it_] = s_fgt[s_ * NMEM + s_seq[k_]]; FS_OUT_FENCE(j_) } } \
+  else for (int it_ = tid; it_ < ns * n_seq; it_ += BT) { const int s_ = mg_ ? (int)FS_UMULHI((unsigned)it_, mg_) : it_, k_ = it_ - s_ * n_seq; \
     g_[it_] = s_fgt[s_ * NMEM + s_seq[k_]]; } }
 )");
+// The sum-product kernel's call-path form spent 44 % of its wave cycles in STAGE_IN_PL (FAMSEQ_PHASE_CLOCK, ten members): 30 two-byte
+// loads per lane, then 30 table look-ups that each touch up to 64 cache lines, both waited for by every wave of the workgroup
+// at once.  "Flat" staging replaces it for whole chunks:
+//   * the chunk's packed PLs are BT * n_seq * 6 contiguous bytes from a 16-byte boundary: fetched as 16-byte pieces, four per
+//     lane, perfectly coalesced — and fetched for the NEXT chunk right after this chunk's message passing, so that they land
+//     during the two output phases (16 registers through phases that have them to spare);
+//   * the pieces go through the top of the row area (free at that moment), from where every lane picks its items' three
+//     16-bit values;
+//   * the first FS_LUT_LDS entries of the pow(10, -k / 10) table live in LDS (8 KB: what two 256-lane workgroups per CU leave
+//     of the 160 KB at ten members): an LDS gather instead of an L1 one; larger PLs (rare) still go to the global table.
+const char kCallFlat[] = R"(
+typedef unsigned fs_v4u __attribute__((ext_vector_type(4)));
+#define RAW_V4 ((BT * NMEM * 6 + 15) / 16)  /* n_seq <= NMEM */
+#define RAW_K ((RAW_V4 + BT - 1) / BT)
+#define FS_LUT(x) ((x) < (unsigned)FS_LUT_LDS ? s_lut[x] : ((x) < 4096u ? lut_[x] : 0.0))
+#define PL_FETCH(S0) { const FS_GLOBAL fs_v4u *r_ = (const FS_GLOBAL fs_v4u *)(call_g->pl + (S0) * call_g->n_seq * 3); \
+  const int nv_ = (BT * call_g->n_seq * 6) / 16; int t_ = tid; FS_HIDE_LANE(t_); \
+  _Pragma("unroll") for (int j_ = 0; j_ < RAW_K; ++j_) if (t_ + j_ * BT < nv_) praw[j_] = r_[t_ + j_ * BT]; }
+#define STAGE_IN_PL_FLAT() { const int n_seq = call_g->n_seq; const FS_GLOBAL double *lut_ = call_g->lut; const int nv_ = (BT * n_seq * 6) / 16; \
+  fs_v4u *raw4_ = (fs_v4u *)((char *)s_io + (BT * ROW * 8 - RAW_V4 * 16)); int t_ = tid; FS_HIDE_LANE(t_); \
+  _Pragma("unroll") for (int j_ = 0; j_ < RAW_K; ++j_) if (t_ + j_ * BT < nv_) raw4_[t_ + j_ * BT] = praw[j_]; \
+  LDS_BARRIER(); \
+  const unsigned short *raw_ = (const unsigned short *)raw4_; \
+  unsigned a_[NMEM], b_[NMEM], d_[NMEM]; \
+  _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) { const int it_ = t_ + j_ * BT, s_ = it_ / NMEM, i_ = it_ - s_ * NMEM, c_ = s_col[i_]; \
+    a_[j_] = b_[j_] = d_[j_] = 0xFFFFu;  /* a member without a column is a missing sample: {1, 1, 1} */ \
+    if (c_ >= 0) { const unsigned short *q_ = raw_ + (s_ * n_seq + c_) * 3; a_[j_] = q_[0]; b_[j_] = q_[1]; d_[j_] = q_[2]; } } \
+  LDS_BARRIER();  /* every lane holds its items: the rows (the raw pieces' place among them) may be written */ \
+  _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) { const int it_ = t_ + j_ * BT, s_ = it_ / NMEM, i_ = it_ - s_ * NMEM; \
+    double v0_ = 1.0, v1_ = 1.0, v2_ = 1.0; \
+    if (!(a_[j_] == 0xFFFFu && b_[j_] == 0xFFFFu && d_[j_] == 0xFFFFu)) { v0_ = FS_LUT(a_[j_]); v1_ = FS_LUT(b_[j_]); v2_ = FS_LUT(d_[j_]); } \
+    double *w_ = s_io + s_ * ROW + 3 * i_; w_[0] = v0_; w_[1] = v1_; w_[2] = v2_; } }
+)";
+
+// FAMSEQ_PHASE_CLOCK (measuring aid): the argument struct gets a counter array and the source a macro that adds the cycles since
+// the previous mark to counter i, once per wave.  Off, the generated text — and so every cached code object — is unchanged.
+std::string with_phase_clock(std::string h) {
+  const std::string at = "magic_n = 0 when n_seq = 1\n};\n";
+  const size_t p = h.find(at);
+  if (p == std::string::npos) throw std::runtime_error("with_phase_clock: the argument struct has moved");
+  h.insert(p + at.size() - 3,
+           "  FS_GLOBAL unsigned long long *phase_clk;  // cycles per phase, one add per wave and phase\n");
+  // (the sums stay in the wave's registers until the kernel ends: an atomic per mark made the kernel four times slower)
+  h += "#define PH(i) { const unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_##i += t_ - ph_last_; ph_last_ = t_; }\n"
+       "#define PH_FLUSH(i) atomicAdd((unsigned long long *)call_g->phase_clk + (i), ph_acc_##i)\n";
+  return h;
+}
 // ... and the arguments that go with it, after the plain ones: all null / 0 on the plain path
 const char kCallArgs[] = ", const struct fs_call_args *__restrict__ call_g";
 
@@ -544,7 +627,7 @@ std::string single_posterior_statements(const Model &m, bool flags_pass, bool st
 //                   BEFORE the single posterior takes over the row.
 std::string kernel_shell(const Model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
-                         bool chrx_loop, int row_doubles, bool call_mode, bool lane_body) {
+                         bool chrx_loop, int row_doubles, bool call_mode, bool lane_body, bool call_ct_out) {
   // ROW: the lane's LDS row, W3 doubles padded to an odd count (conflict-free ds_read_b64); a
   // generator may ask for more (spare slots it uses itself), odd again
   const int N = m.n_members, W3 = 3 * N, ROW = (row_doubles > 0 ? row_doubles : W3) | 1;
@@ -642,9 +725,30 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
     << "#define STAGE_PRE() { \\\n"
     << "  if (v16) { WALK16(s_io[a] = pre[k].x; s_io[a1] = pre[k].y) } \\\n"
     << "  else { WALK8(s_io[a] = ((double *)pre)[k]) } }\n";
+  // FAMSEQ_PHASE_CLOCK (measuring aid, call path only): the waves add the cycles of each phase of the chunk loop to counters
+  // behind call_g->phase_clk — 0 stage in, 1 single posterior + Phred, 2 GPP out, 3 message passing, 4 Phred of the marginals,
+  // 5 FPP / FGT / status out (famseq_bn_call_batch prints the shares).  Without the variable the source is unchanged.
+  const bool phase_clock = call_mode && std::getenv("FAMSEQ_PHASE_CLOCK") != nullptr;
+  // How much of the output work the scheduler sees at once (kCallHelpers): logarithms of two members or of one per basic block,
+  // the stage-out walk with the row width as a constant or as read from the arguments.  More at once = more registers.
+  int phred_group = 2;
+  const bool ct_out = call_ct_out;
+  if (const char *e = std::getenv("FAMSEQ_CALL_PHRED_GROUP")) phred_group = std::atoi(e) == 1 ? 1 : 2;  // tuning aid
+  auto PH = [&](int i) { return phase_clock ? "    PH(" + std::to_string(i) + ");\n" : std::string(); };
   if (call_mode)
-    s << "#define NMEM " << N << "\n" << kCallHelpers
+    s << "#define NMEM " << N << "\n#define NSEQ_CT " << std::max(1, (int)std::count(m.sequenced.begin(), m.sequenced.end(), 1)) << "\n"
+      // (measured, ns per 1 M sites, hoisted / formed again: sum-product form 5 members 125 / 133, trio 70 / 77, quad 96 / 103, ten 252 with
+      // the leaner walk / 249; enumeration form trio 66 / 88, quad 105 / 108, five members 162 / 143)
+      << "#define FS_OPAQUE_LANE " << (N >= (entry == "famseq_elim" ? 7 : 5) ? 1 : 0) << "\n"
+      << "#define FS_PHRED_GROUP " << phred_group << "\n#define FS_CT_OUT " << (ct_out ? 1 : 2) << "\n"
+      << (phase_clock ? with_phase_clock(kCallHelpers) : kCallHelpers)
       << "#define STAGE_IN_ANY() { if (packed_in) { STAGE_IN_PL(); } else { STAGE_IN(lk_g); } }\n";
+  // flat staging of the packed PLs (kCallFlat): the sum-product kernel's call form; FAMSEQ_CALL_FLAT=0 (tuning aid) keeps the item walk
+  bool flat_pl = call_mode && entry == "famseq_elim" && bt % 8 == 0;  // (BT * n_seq * 6 bytes are whole 16-byte pieces)
+  if (const char *e = std::getenv("FAMSEQ_CALL_FLAT")) flat_pl = flat_pl && std::atoi(e) != 0;
+  int lut_lds = 1024;
+  if (const char *e = std::getenv("FAMSEQ_CALL_LUT_LDS")) lut_lds = std::max(1, std::atoi(e));  // tuning aid
+  if (flat_pl) s << "#define FS_LUT_LDS " << lut_lds << "\n" << kCallFlat;
 
   if (!regs_l)
     for (int p = 0; p < N; ++p)
@@ -653,7 +757,8 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
     << "(const double *__restrict__ lk_g,\n"
     << "    const unsigned char *__restrict__ flags_g, double *__restrict__ post_g, double *__restrict__ single_g,\n"
     << "    unsigned char *__restrict__ status_g, long n_sites, const double *__restrict__ tc_g, double lc" << (call_mode ? kCallArgs : "") << ") {\n"
-    << "  __shared__ double s_io[BT * ROW];  // one padded row per lane: conflict-free ds_read_b64\n"
+    << (flat_pl ? "  __shared__ __attribute__((aligned(16))) double s_io[BT * ROW];  // one padded row per lane: conflict-free ds_read_b64\n"
+                : "  __shared__ double s_io[BT * ROW];  // one padded row per lane: conflict-free ds_read_b64\n")
     << "  __shared__ double s_tc[432];\n"
     << "  const int tid = threadIdx.x;\n"
     << "  for (int i = tid; i < 432; i += BT) s_tc[i] = tc_g[i];\n"
@@ -679,13 +784,21 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
                     "  __shared__ __attribute__((aligned(16))) double s_lt[258];  // fs_phred's table: one 16-byte LDS read per logarithm\n"
                     "  for (int i = tid; i < 258; i += BT) s_lt[i] = fs_logtab[i];\n"
                     "  for (int i = tid; i < NMEM; i += BT) { s_col[i] = call_g->col[i]; s_seq[i] = i < call_g->n_seq ? call_g->seq[i] : 0; }\n"
+                  : "")
+    << (flat_pl ? "  __shared__ double s_lut[FS_LUT_LDS];  // pow(10, -k / 10), k < FS_LUT_LDS\n"
+                  "  if (packed_in) for (int i = tid; i < FS_LUT_LDS; i += BT) s_lut[i] = call_g->lut[i];\n"
+                  "  const bool flat_ok = packed_in && ((unsigned long)call_g->pl & 15) == 0;\n"
+                  "  fs_v4u praw[RAW_K];  // the NEXT chunk's packed PLs, fetched ahead\n"
+                  "  bool have_raw = false;\n"
 
                   : "")
+    << (phase_clock ? "  unsigned long long ph_last_ = 0, ph_acc_0 = 0, ph_acc_1 = 0, ph_acc_2 = 0, ph_acc_3 = 0, ph_acc_4 = 0, ph_acc_5 = 0, ph_acc_6 = 0;\n" : "")
     << (strided ? "  for (long ch = c_lo; ch < c_hi; ch += gridDim.x) {\n" : "  for (long ch = c_lo; ch < c_hi; ++ch) {\n")
     << "    const long site0 = ch * BT;\n"
     << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
     << "    const int nel = ns * W3;\n"
     << "    const bool whole = ns == BT;\n"
+    << (phase_clock ? "    ph_last_ = __builtin_readcyclecounter();\n" : "")
     << "    LDS_BARRIER();\n";
   if (prefetch) {
     // the next chunk's rows were requested during the previous chunk's output phases
@@ -694,9 +807,10 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
       s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
   } else {
-    s << (call_mode ? "    STAGE_IN_ANY();\n" : "    STAGE_IN(lk_g);\n");
+    s << (flat_pl ? "    if (flat_ok && whole) { if (!have_raw) { PL_FETCH(site0); } STAGE_IN_PL_FLAT(); } else { STAGE_IN_ANY(); }\n"
+                  : (call_mode ? "    STAGE_IN_ANY();\n" : "    STAGE_IN(lk_g);\n"));
   }
-  s << "    LDS_BARRIER();\n"
+  s << "    LDS_BARRIER();\n" << PH(0)
     << "    const int fl = (tid < ns && flags_g) ? (flags_g[site0 + tid] & 3) : 0;\n"
     << "    const double *tcf = s_tc + fl * 108;\n"
     << "    bool single_fail = false, full = false, bn_fail = false;\n";
@@ -708,9 +822,9 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
     single_pass(true, true);
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << (call_mode ? "    ROW_TO_CALL();  // the single posterior as printed (GPP) and its arg-max (FGT of shortcut sites)\n" : "")
-      << "    LDS_BARRIER();\n"
+      << "    LDS_BARRIER();\n" << PH(1)
       << (call_mode ? "    if (call_g->gpp) { STAGE_OUT_CALL(call_g->gpp); }\n" : "    if (single_g) { STAGE_OUT(single_g); }\n")
-      << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n";
+      << "    LDS_BARRIER();  // single rows are stored; sites that need the full computation overwrite theirs\n" << PH(2);
     if (chrx_loop)
       // (as for the sum-product body below) the children's transmission entries depend on the site's chrX bit only: the
       // body reads them through the wave-uniform pointer tcx (scalar loads) and runs once per chrX value present in the wave
@@ -732,18 +846,19 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
     if (prefetch && !early)
       s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
         << "    if (have_pre) { PREFETCH(lk_g); }\n";
-    s
-      << "    LDS_BARRIER();\n"
+    s << (flat_pl ? "    have_raw = flat_ok && ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // the next chunk, if it is a whole one: its packed PLs land during the output phases\n"
+                  "    if (have_raw) { PL_FETCH(site0 + BT); }\n" : "")
+      << "    LDS_BARRIER();\n" << PH(3)
       << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
                     : "    STAGE_OUT(post_g);\n")
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
-      << "  }\n}\n";
+      << PH(5) << (phase_clock ? "  }\n  if ((tid & 63) == 0 && call_g->phase_clk) { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); }\n}\n" : "  }\n}\n");
   } else {
     // Outputs are staged through the same LDS rows as the input (coalesced 8 B/lane stores).
     // Writing each lane's row straight from registers was measured 20 % slower on MI355X
     // (64 partial-line requests per store instruction), so the extra barriers stay.
     single_pass(true, false);
-    s << "    double q[W3];\n";
+    s << PH(6) << "    double q[W3];\n";
     if (chrx_loop) {
       // The transmission entries depend on the site's chrX bit only.  The body reads them through a
       // wave-uniform pointer (scalar loads: no LDS traffic, no VGPRs) and runs once per chrX value
@@ -768,21 +883,23 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
       // chunk's two output phases run (the barriers below do not wait for vmcnt)
       s << "    have_pre = " << (strided ? "ch + gridDim.x < c_hi && (ch + gridDim.x + 1) * BT <= n_sites" : "ch + 1 < c_hi && site0 + 2 * BT <= n_sites") << ";  // only whole chunks are prefetched\n"
       << "    if (have_pre) { PREFETCH(lk_g); }\n";
+    s << PH(3) << (flat_pl ? "    have_raw = flat_ok && ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // the next chunk, if it is a whole one: its packed PLs land during the output phases\n"
+                  "    if (have_raw) { PL_FETCH(site0 + BT); }\n" : "");
     single_pass(false, true);  // now the single posterior may take the row over
     s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
       << (call_mode ? "    ROW_TO_CALL();  // the single posterior as printed (GPP) and its arg-max (FGT of shortcut sites)\n" : "")
-      << "    LDS_BARRIER();\n"
+      << "    LDS_BARRIER();\n" << PH(1)
       << (call_mode ? "    if (call_g->gpp) { STAGE_OUT_CALL(call_g->gpp); }\n" : "    if (single_g) { STAGE_OUT(single_g); }\n")
-      << "    LDS_BARRIER();  // single rows are stored; sites that ran the full computation overwrite theirs\n"
+      << "    LDS_BARRIER();  // single rows are stored; sites that ran the full computation overwrite theirs\n" << PH(2)
       << "    if (full && !single_fail) {\n"
       << "#pragma unroll\n      for (int k = 0; k < W3; ++k) row[k] = bn_fail ? kNaN : q[k];\n"
       << (call_mode ? "      ROW_TO_CALL();  // the BN posterior as printed (FPP) and the genotype call\n" : "")
       << "    }\n"
-      << "    LDS_BARRIER();\n"
+      << "    LDS_BARRIER();\n" << PH(4)
       << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
                     : "    STAGE_OUT(post_g);\n")
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
-      << "  }\n}\n";
+      << PH(5) << (phase_clock ? "  }\n  if ((tid & 63) == 0 && call_g->phase_clk) { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); }\n}\n" : "  }\n}\n");
   }
   return s.str();
 }
@@ -900,15 +1017,17 @@ std::string elim_source(const Model &m, int variant, bool call_mode) {
   // Where the likelihoods live during the message passing: re-read from the lane's LDS row at each use (short live ranges:
   // what the narrow pedigrees' kernels want, they run at two or more waves per SIMD), or — registers-first — read once into
   // registers, the row then being the output stage (no q[] array, a tenth of the LDS reads, all of them issued together).
-  bool regs_l = variant >= 4 && (!call_mode || std::getenv("FAMSEQ_ELIM_CALL_REGS"));
+  bool regs_l = call_mode ? std::getenv("FAMSEQ_ELIM_CALL_REGS") != nullptr : variant >= 4;  // (the call path: r = 0 unless the tuning aid says otherwise)
   if (const char *e = std::getenv("FAMSEQ_ELIM_REGS")) regs_l = std::atoi(e) != 0 && !call_mode;  // tuning aid
+  const bool ct_out = !(call_mode && (variant & 4));
   variant &= 3;  // the fence level
   const std::string what = "exact sum-product over " + std::to_string(g.fam.size()) + " nuclear families" +
                            (g.cut.empty() ? "" : ", conditioned on " + std::to_string(g.cut.size()) + " member(s)") + ", variant " +
-                           std::to_string(variant + (regs_l ? 4 : 0)) + (regs_l ? " (likelihoods in registers)" : "") + (call_mode ? ", call path" : "");
+                           std::to_string(variant + (call_mode ? (ct_out ? 0 : 4) : (regs_l ? 4 : 0))) + (regs_l ? " (likelihoods in registers)" : "") +
+                           (call_mode ? ", call path" : "");
   return kernel_shell(m, "famseq_elim", what,
                       Emitter(m, g, variant < 2 ? variant : 2, /*scalar_t=*/variant >= 1, regs_l ? "row" : "q").body(), bt, min_waves,
-                      regs_l, variant >= 3, /*chrx_loop=*/variant >= 1, 0, call_mode);
+                      regs_l, variant >= 3, /*chrx_loop=*/variant >= 1, 0, call_mode, /*lane_body=*/false, ct_out);
 }
 
 }  // namespace famseq

@@ -24,7 +24,9 @@ int elim_conditioned_members(const Model &m);
 // members: profiles/r03a/exp_elim_registers_first*.txt).  jit_pick_variant takes the first that does not spill, from
 // elim_first_variant on.  The call-path form has the r = 0 family only.
 constexpr int kElimVariants = 12;  // 8..11 (r = 2): no LDS staging at all, rows straight from and to global memory (the widest pedigrees)
-constexpr int kElimCallVariants = 4;
+// The call-path form: fence level f = v & 3 of the r = 0 family, and (v & 4) how its stage-out walks the rows — 0: the row width a
+// constant (no per-step bound to test, every load of the walk in flight together; more registers), 4: read from the arguments.
+constexpr int kElimCallVariants = 8;
 // call_mode: the fused call path's form (packed PLs or fp64 rows in; GPP / FPP / FGT / status out)
 std::string elim_source(const Model &m, int variant, bool call_mode = false);
 int elim_block_threads(const Model &m, bool call_mode = false);
@@ -36,7 +38,8 @@ extern const char kCallArgs[];     // ... and the kernel arguments that go with 
 std::string single_posterior_statements(const Model &m, bool flags_pass, bool store, bool fence_single);
 std::string kernel_shell(const Model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,
-                         bool chrx_loop = false, int row_doubles = 0, bool call_mode = false, bool lane_body = false);
+                         bool chrx_loop = false, int row_doubles = 0, bool call_mode = false, bool lane_body = false,
+                         bool call_ct_out = true);
 
 }  // namespace famseq
 #endif

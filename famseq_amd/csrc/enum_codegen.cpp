@@ -883,7 +883,7 @@ std::string grouped_shell(const Model &m, const std::string &comment, const std:
 
 }  // namespace
 
-std::string enumgen_source(const Model &m, int variant, int group_digits, bool call_mode) {
+std::string enumgen_source(const Model &m, int variant, int group_digits, bool call_mode, bool call_ct_out) {
   int cap = (group_digits == 0 && variant < 2) ? 7 : 6;  // see kEnumVariants
   if (const char *e = std::getenv("FAMSEQ_LANE_CAP")) cap = std::atoi(e);  // tuning aid
   const Shape s = choose_shape(m, cap);
@@ -936,7 +936,10 @@ std::string enumgen_source(const Model &m, int variant, int group_digits, bool c
     what = "3^N enumeration, " + std::to_string(group) + " lanes per site (" + std::to_string(group_digits) + " of " +
            std::to_string(s.outer.size()) + " looped members' digits on lanes), " + std::to_string(s.unrolled.size()) +
            " unrolled members, variant " + std::to_string(variant);
-  int min_waves = group_digits == 0 ? 1 : bt / 128;
+  // (the call-path form of a small pedigree's kernel: two waves per SIMD at least — with 512 registers to fill, its output stages'
+  // batched loads took the five-member kernel from two waves to one, 0.156 -> 0.203 ms per 1 M sites; bounded, the variant
+  // contest sees the spill and takes the leaner stage-out)
+  int min_waves = group_digits == 0 ? (call_mode && m.n_members <= 6 ? 2 : 1) : bt / 128;
   if (const char *e = std::getenv("FAMSEQ_LANE_MINWAVES")) min_waves = std::atoi(e);  // tuning aid
   // Transmission entries through scalar loads, and the innermost loop's loads one step ahead (see Gen): the one-lane-per-site
   // forms of pedigrees that have looped members; the lanes-per-site forms keep the per-lane LDS table.  Round 3, measured
@@ -953,7 +956,7 @@ std::string enumgen_source(const Model &m, int variant, int group_digits, bool c
   if (call_mode) what += ", call path";
   if (late)  // regs_l = false: the shell's compute-first flow; variant 0 / 1 as below
     return kernel_shell(m, "famseq_enum_lane", what + ", compute-first shell", gen.body(), bt, min_waves, /*regs_l=*/false, (variant & 1) != 0,
-                        /*chrx_loop=*/false, row_len, call_mode, /*lane_body=*/true);
+                        /*chrx_loop=*/false, row_len, call_mode, /*lane_body=*/true, call_ct_out);
   const bool fence_single = variant & 1;
   if (group > 1) {
     if (call_mode) throw std::runtime_error("enumeration codegen: the lanes-per-site form has no call path");
@@ -963,7 +966,7 @@ std::string enumgen_source(const Model &m, int variant, int group_digits, bool c
   // regs_l: LDS-resident likelihoods measured 17% slower.  variant 0: the members of the single
   // posterior overlap, 1: fenced one from the other (fewer registers)
   return kernel_shell(m, "famseq_enum_lane", what, gen.body(), bt, min_waves, /*regs_l=*/true, fence_single,
-                      /*chrx_loop=*/scalar_t, row_len, call_mode);
+                      /*chrx_loop=*/scalar_t, row_len, call_mode, /*lane_body=*/false, call_ct_out);
 }
 
 }  // namespace famseq

@@ -19,7 +19,8 @@ constexpr int kEnumVariants = 4;
 // group_digits = d > 0: lanes-per-site mode for small batches — 3^d consecutive lanes share a site, each
 // taking one combination of the d outermost looped members' digits (d <= enumgen_max_group_digits)
 constexpr int kEnumMaxGroupDigits = 4;
-std::string enumgen_source(const Model &m, int variant, int group_digits = 0, bool call_mode = false);
+// call_ct_out (call path only): the stage-out walk with the row width as a constant (see kElimCallVariants)
+std::string enumgen_source(const Model &m, int variant, int group_digits = 0, bool call_mode = false, bool call_ct_out = true);
 int enumgen_max_group_digits(const Model &m);
 // true when the call-path form of the one-lane-per-site kernel re-reads some members' likelihoods from the
 // fp64 rows in global memory inside its loops (wide pedigrees whose LDS row cannot hold them): such a kernel

@@ -18,7 +18,9 @@
 // Needs FS_RCP / FS_FREXP_MANT / FS_FREXP_EXP / FS_HI32 / FS_IS_POS_FINITE / FS_KEEP_BRANCH (device builtins; the host
 // test shims them) and the type fs_v2d (two doubles, 16-byte aligned).
 FS_PHRED_DEF(
-static __device__ __forceinline__ double fs_phred(double p, const double *lt) {
+/* the arithmetic alone: right for a positive finite p, finite garbage for anything else (no branch, so that several of
+   these in one basic block overlap their table reads and FMA chains) */
+static __device__ __forceinline__ double fs_phred_fast(double p, const double *lt) {
   const double m0 = FS_FREXP_MANT(p);
   int e = FS_FREXP_EXP(p);
   const unsigned a = (((((unsigned)FS_HI32(m0)) >> 12) & 0xFFu) + 1u) << 3 & ~15u;
@@ -30,10 +32,17 @@ static __device__ __forceinline__ double fs_phred(double p, const double *lt) {
   t = __builtin_fma(t, r, 1.0 / 3);
   t = __builtin_fma(t, r, -0.5);
   const double ln1p = __builtin_fma(r * r, t, r);
-  double q = __builtin_fabs(__builtin_fma(ln1p, -4.3429448190325175, __builtin_fma((double)e, -3.0102999566398120, tk.y)));
+  return __builtin_fabs(__builtin_fma(ln1p, -4.3429448190325175, __builtin_fma((double)e, -3.0102999566398120, tk.y)));
+}
+/* what is printed for the p the arithmetic is not for (q = fs_phred_fast's answer, kept when p is positive and finite) */
+static __device__ __forceinline__ double fs_phred_fix(double p, double q) {
+  return FS_IS_POS_FINITE(p) ? q : (p == 0.0 ? 99999.0 : (p == __builtin_inf() ? p : __builtin_nan("")));
+}
+static __device__ __forceinline__ double fs_phred(double p, const double *lt) {
+  double q = fs_phred_fast(p, lt);
   if (!FS_IS_POS_FINITE(p)) {
     FS_KEEP_BRANCH();
-    q = p == 0.0 ? 99999.0 : (p == __builtin_inf() ? p : __builtin_nan(""));
+    q = fs_phred_fix(p, q);
   }
   return q;
 }

@@ -83,10 +83,17 @@ extern "C" void famseq_enum_lane(const double *lk, const unsigned char *fl, doub
 """
 
 
+def portable(src: str) -> str:
+    """Device-only spellings both shims replace: compiler pins (no arithmetic in them) and clang's vector types."""
+    src = re.sub(r"#define FS_HIDE_LANE\(t_\).*", "#define FS_HIDE_LANE(t_) (void)0", src)
+    src = src.replace("typedef unsigned fs_v4u __attribute__((ext_vector_type(4)));", "struct fs_v4u { unsigned x, y, z, w; };")
+    return src.replace("__builtin_amdgcn_sched_barrier(0);", "")
+
+
 def host_source(src: str, threads=False) -> str:
     src = re.sub(r"#define FS_KEEP_BRANCH\(\) asm.*", "", src)  # device default; the host shim has its own
     src = src.replace("typedef double fs_v2d __attribute__((ext_vector_type(2)));", "")
-    src = src.replace("__builtin_amdgcn_sched_barrier(0);", "")  # scheduling pins: no code on the device either
+    src = portable(src)
     if threads:
         src = src.replace("#include <hip/hip_runtime.h>", SHIM_THREADS)
         src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() pthread_barrier_wait(&wg_barrier_)", src)
@@ -432,10 +439,11 @@ def _threaded_call_kernel(model, elim, bt, cache, monkeypatch):
     obj, entry = ((plan["elim_call_code_object"], "famseq_elim") if elim else (plan["enum_lane_call_code_object"], "famseq_enum_lane"))
     src = open(obj[:-6] + ".hip").read()
     reads_rows = "lg[" in src
+    assert ("STAGE_IN_PL_FLAT" in src) == bool(elim)  # the flat staging of packed PLs: the sum-product form's
     shim = SHIM_THREADS.replace("#define famseq_enum_lane famseq_enum_lane_one_thread", "#define %s kernel_one_thread_" % entry)
     shim += SHIM_CALL + "#define __builtin_amdgcn_ballot_w64(p) ((unsigned long)(p))\n"
     src = re.sub(r"#define FS_KEEP_BRANCH\(\) asm.*", "", src).replace("typedef double fs_v2d __attribute__((ext_vector_type(2)));", "")
-    src = src.replace("#include <hip/hip_runtime.h>", shim).replace("__builtin_amdgcn_sched_barrier(0);", "")
+    src = portable(src).replace("#include <hip/hip_runtime.h>", shim)
     src = re.sub(r"#define LDS_BARRIER\(\).*", "#define LDS_BARRIER() pthread_barrier_wait(&wg_barrier_)", src)
     src = src.replace("typedef double v2d __attribute__((ext_vector_type(2)));", "").replace("__attribute__((address_space(3)))", "").replace("__attribute__((address_space(1)))", "")
     src = re.sub(r'asm volatile\(""[^\n;]*\);', "", src.replace('extern "C" __global__', "static"))
@@ -529,6 +537,10 @@ def test_call_path_forms_as_whole_workgroups(seed, tmp_path, monkeypatch):
             assert np.all(np.abs(pa - pb)[diff] <= 1e-9 * pb[diff]), (seed, elim, S)
             assert np.all(a[2][~ok] == -1) and np.all(np.isnan(a[1][~ok]))
             if not reads_rows:
+                # (16-byte aligned, as the library's device buffers are: whole chunks of the sum-product form then take the flat
+                # staging — coalesced 16-byte pieces through the top of the row area, the next chunk's fetched ahead: S = 19 is two
+                # whole chunks and a ragged one)
+                assert pl.ctypes.data % 16 == 0
                 b = run(pl_in=pl)
                 for x, y in zip(a, b):
                     assert np.array_equal(x, y, equal_nan=True), (seed, elim, S)
