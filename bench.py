@@ -266,6 +266,62 @@ def side_wide(fs, torch, dev, stream, n_members, steps, warmup, sites):
                          "kernel_ms": k_ms, "bytes_per_site": bps, "stream_probe_GBps": probe, "frac_of_stream_probe": ach / probe}}
 
 
+def side_call_path(fs, torch, dev, stream, workload, steps, warmup, sites):
+    """The fused call path on resident buffers (famseq_bn_call_batch_device): packed integer PLs in, GPP / FPP / FGT / status
+    out — what `FamSeq vcf` and `FamSeq PL` launch per block — and, timed apart, the same call with the text records as well
+    (famseq_bn_call_text_batch's device side).  Same contract as the other sub-objects: resident inputs, HIP events on the
+    launch stream.  Engine: the sum-product form (`-method 2`), the memory-bound one; bytes per site 6 n_seq + 1 in,
+    49 n_seq + 1 out (text: + 80 n_seq out, 49 n_seq read again)."""
+    import numpy as np
+
+    cfg, _ = WORKLOADS[workload]
+    ped = fs.synthetic_pedigree(workload)
+    n = ped.n
+    mo, fa = ped.relations()
+    pl, known, _ = fs.synth.gen_sites(mo, fa, sites, fs.synth.SEED_BASE + cfg)
+    d_pl = torch.from_numpy(pl.astype(np.uint16).view(np.int16)).to(dev)
+    d_fl = torch.from_numpy(known.astype(np.uint8)).to(dev)
+    d_gpp = torch.empty((sites, n, 3), dtype=torch.float64, device=dev)
+    d_fpp = torch.empty_like(d_gpp)
+    d_fgt = torch.empty((sites, n), dtype=torch.int8, device=dev)
+    d_st = torch.full((sites,), 77, dtype=torch.uint8, device=dev)
+    d_text = torch.zeros((sites, n, fs.TEXT_STRIDE), dtype=torch.uint8, device=dev)
+    seq = np.arange(n, dtype=np.int32)
+    ctx = fs.Context(fs.make_model(ped), device=dev.index or 0, engine=fs.ENGINE_ELIM)
+
+    def timed(text):
+        def step():
+            ctx.bn_call_batch_device(sites, seq, d_pl16=d_pl.data_ptr(), d_flags=d_fl.data_ptr(), d_gpp=d_gpp.data_ptr(),
+                                     d_fpp=d_fpp.data_ptr(), d_fgt=d_fgt.data_ptr(), d_status=d_st.data_ptr(),
+                                     d_text=d_text.data_ptr() if text else 0, stream=stream.cuda_stream)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for k in range(steps):
+            ev[k][0].record(stream)
+            step()
+            ev[k][1].record(stream)
+        torch.cuda.synchronize()
+        return sum(a_.elapsed_time(b_) for a_, b_ in ev) / steps
+
+    ms = timed(False)
+    ms_text = timed(True)
+    ok = int((d_st != 0).sum().item()) == 0 and bool((d_fpp >= 0).all().item()) and bool((d_fgt >= 0).all().item())
+    ln = d_text[:, :, -1]
+    ok = ok and int(ln.min().item()) >= 16 and int(ln.max().item()) <= 76
+    ctx.close()
+    bps = 6 * n + 1 + 49 * n + 1
+    ach = sites * bps / (ms * 1e-3) / 1e9
+    return {"workload": "%s, %d seeded synthetic sites as packed integer PLs, fused call path (posterior + Phred + genotype call in one "
+                        "launch), engine = sum-product" % (workload, sites),
+            "kernel": "famseq_elim, call-path form", "kernel_ms": ms, "value": sites / (ms * 1e-3), "unit": "sites/s", "steps": steps,
+            "outputs_valid": ok, "bytes_per_site": bps,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS},
+            "with_text_records_ms": ms_text, "text_kernel_ms": ms_text - ms,
+            "note": "latency- and VALU-paced at two waves per SIMD (60 logarithms and the message passing per site), not by HBM: DESIGN.md 2.4"}
+
+
 class quiet_stdout:
     """Send whatever is written to file descriptor 1 to stderr for a while: RCCL prints its version banner
     and gloo its connection messages on stdout from C++, and stdout is for the ONE JSON line."""
@@ -615,6 +671,8 @@ def main():
             out["configs_4_ped15"] = side_config(fs, torch, dev, stream, "ped15", 2, 1)
             # beyond the enumeration: the 32-member pedigree through the sum-product engine (4.6 GB of traffic per step)
             out["elim_N32"] = side_wide(fs, torch, dev, stream, 32, max(a.steps, 10), max(a.warmup, 3), 2_000_000)
+            # what the command line launches: the fused call path on packed PLs, and the text records behind it
+            out["call_path"] = side_call_path(fs, torch, dev, stream, "ped10", max(a.steps, 20), max(a.warmup, 5), 1_000_000)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ped, cfg, a.cpu_seconds, n)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]

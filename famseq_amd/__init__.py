@@ -79,7 +79,7 @@ ABI_SYMBOLS = [
     "famseq_create_pedigree",
     "famseq_destroy", "famseq_last_error", "famseq_set_option", "famseq_plan_json",
     "famseq_bn_batch", "famseq_bn_batch_sharded", "famseq_bn_batch_device", "famseq_bn_batch_device_sharded",
-    "famseq_bn_call_batch", "famseq_bn_call_text_batch", "famseq_format_probe", "famseq_alloc_pinned", "famseq_free_pinned", "famseq_stream_probe",
+    "famseq_bn_call_batch", "famseq_bn_call_text_batch", "famseq_bn_call_batch_device", "famseq_format_probe", "famseq_alloc_pinned", "famseq_free_pinned", "famseq_stream_probe",
     "famseq_call_genotypes",
 ]
 PL_MISSING = 0xFFFF
@@ -140,6 +140,8 @@ def lib():
     L.famseq_bn_call_batch.restype = C.c_int
     L.famseq_bn_call_text_batch.argtypes = [C.c_void_p, C.c_int64, dp, C.POINTER(C.c_uint16), bp, ip, C.c_int32, C.c_char_p, bp]
     L.famseq_bn_call_text_batch.restype = C.c_int
+    L.famseq_bn_call_batch_device.argtypes = [C.c_void_p, C.c_int64, vp, vp, vp, ip, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.famseq_bn_call_batch_device.restype = C.c_int
     L.famseq_format_probe.argtypes = [C.c_void_p, C.c_int64, dp, C.c_char_p]
     L.famseq_format_probe.restype = C.c_int
     L.famseq_stream_probe.argtypes = [C.c_void_p, C.c_int64, vp, vp, vp, vp]
@@ -294,6 +296,15 @@ class Context:
                                              text.ctypes.data_as(C.c_char_p), _p(status, C.c_uint8))
         self._check(rc, "famseq_bn_call_text_batch")
         return text, status
+
+    def bn_call_batch_device(self, n_sites, seq_members, d_lk=0, d_pl16=0, d_flags=0, d_gpp=0, d_fpp=0, d_fgt=0, d_status=0, d_text=0,
+                             stream=0):
+        """The call path on resident buffers (raw device pointers as ints; 0 = not given); enqueues on `stream` and returns."""
+        seq = np.ascontiguousarray(seq_members, dtype=np.int32)
+        rc = lib().famseq_bn_call_batch_device(self._h, int(n_sites), d_lk or None, d_pl16 or None, d_flags or None, _p(seq, C.c_int32),
+                                               len(seq), d_gpp or None, d_fpp or None, d_fgt or None, d_status or None, d_text or None,
+                                               stream or None)
+        self._check(rc, "famseq_bn_call_batch_device")
 
     def g6_probe(self, values):
         """The device formatter alone (famseq_format_probe): -> list of bytes, one per value."""

@@ -107,6 +107,16 @@ struct famseq_ctx {
   int32_t *d_seq = nullptr, *d_col = nullptr;
   CallIO *d_call[kSlots] = {};  // the generated kernels' call-path arguments, one per slot
   unsigned long long *d_phase = nullptr;  // FAMSEQ_PHASE_CLOCK: kPhases counters
+  // device-resident call path (famseq_bn_call_batch_device): its own argument block, what it holds, and scratch rows for
+  // batches the fused kernels do not serve (separate unpack / posterior / Phred stages)
+  CallIO *d_call_dev = nullptr;
+  CallIO call_dev_host{};
+  bool call_dev_valid = false;
+  double *dev_tmp[5] = {};  // lk, post, single, gpp, fpp
+  int8_t *dev_tmp_fgt = nullptr;
+  uint8_t *dev_tmp_status = nullptr;
+  int64_t dev_tmp_sites = 0;
+  int dev_tmp_seq = 0;
   std::vector<int32_t> seq_members;
   std::string tune_report;  // what famseq_set_option "tune" measured (famseq_plan_json "tune")
   std::string err, json;
@@ -565,6 +575,12 @@ extern "C" void famseq_destroy(famseq_ctx *c) {
     if (c->d_col) (void)hipFree(c->d_col);
     for (int s = 0; s < famseq_ctx::kSlots; ++s)
       if (c->d_call[s]) (void)hipFree(c->d_call[s]);
+    if (c->d_call_dev) (void)hipFree(c->d_call_dev);
+    if (c->d_phase) (void)hipFree(c->d_phase);
+    for (double *q : c->dev_tmp)
+      if (q) (void)hipFree(q);
+    if (c->dev_tmp_fgt) (void)hipFree(c->dev_tmp_fgt);
+    if (c->dev_tmp_status) (void)hipFree(c->dev_tmp_status);
     for (int s = 0; s < famseq_ctx::kStages; ++s)
       if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
     for (int s = 0; s < famseq_ctx::kSlots; ++s)
@@ -1188,5 +1204,90 @@ extern "C" int famseq_format_probe(famseq_ctx *c, int64_t n, const double *value
   (void)hipFree(d_in);
   if (d_out) (void)hipFree(d_out);
   if (e != hipSuccess) return fail(c, FAMSEQ_E_HIP, std::string("famseq_format_probe: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// The call path on buffers that are resident already (a pipeline that keeps its packed PLs, or its results, in HBM; bench.py's
+// `call_path` line): the same kernels as famseq_bn_call_batch, enqueued on the caller's stream, nothing copied.
+extern "C" int famseq_bn_call_batch_device(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint16_t *d_pl16,
+                                           const uint8_t *d_flags, const int32_t *seq_members, int32_t n_seq, double *d_gpp,
+                                           double *d_fpp, int8_t *d_fgt, uint8_t *d_status, char *d_text, void *stream_) {
+  if (!c) return FAMSEQ_E_ARG;
+  if (n_sites < 0 || (n_sites > 0 && ((d_lk == nullptr) == (d_pl16 == nullptr))))
+    return fail(c, FAMSEQ_E_ARG, "exactly one of d_lk / d_pl16 must be given");
+  if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "context was created without a device; there is no CPU path");
+  if (n_seq < 1) return fail(c, FAMSEQ_E_ARG, "n_seq must be >= 1");
+  if (d_text && (reinterpret_cast<uintptr_t>(d_text) & 15)) return fail(c, FAMSEQ_E_ARG, "d_text must be 16-byte aligned");
+  HIP_TRY(c, hipSetDevice(c->device));
+  {
+    const int rc = set_sequenced(c, seq_members, n_seq);
+    if (rc != 0) return rc;
+  }
+  if (n_sites == 0) return 0;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int N = c->model.n_members;
+  const bool want_text = d_text != nullptr;
+  // what the stages write: the caller's arrays, or scratch of this context's for those the caller does not ask for but a later
+  // stage reads (the text kernel reads all three) or a separate-stages batch passes through (fp64 rows in and out)
+  const size_t row = size_t(3) * N * sizeof(double), crow = size_t(3) * n_seq * sizeof(double);
+  if (c->dev_tmp_sites < n_sites || c->dev_tmp_seq < n_seq) {
+    HIP_TRY(c, hipStreamSynchronize(stream));  // nothing of an earlier call may still use what is freed here
+    const int64_t cap = std::max(n_sites, c->dev_tmp_sites);
+    const int seqcap = std::max<int>(n_seq, c->dev_tmp_seq);
+    for (double *&q : c->dev_tmp) {
+      if (q) (void)hipFree(q);
+      q = nullptr;
+    }
+    if (c->dev_tmp_fgt) (void)hipFree(c->dev_tmp_fgt);
+    if (c->dev_tmp_status) (void)hipFree(c->dev_tmp_status);
+    c->dev_tmp_fgt = nullptr, c->dev_tmp_status = nullptr, c->dev_tmp_sites = 0;
+    for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp[i]), size_t(cap) * row));
+    for (int i = 3; i < 5; ++i) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp[i]), size_t(cap) * 3 * seqcap * sizeof(double)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp_fgt), size_t(cap) * seqcap));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp_status), size_t(cap)));
+    c->dev_tmp_sites = cap, c->dev_tmp_seq = seqcap;
+  }
+  (void)crow;
+  double *gpp = d_gpp ? d_gpp : (want_text ? c->dev_tmp[3] : nullptr), *fpp = d_fpp ? d_fpp : (want_text ? c->dev_tmp[4] : nullptr);
+  int8_t *fgt = d_fgt ? d_fgt : (want_text ? c->dev_tmp_fgt : nullptr);
+  uint8_t *status = d_status ? d_status : c->dev_tmp_status;
+  if (d_pl16 && !c->d_lut) {  // pow(10,-k/10) through the host's libm, as file.cpp:589 computes it
+    std::vector<double> lut(kPlLutSize);
+    for (int k = 0; k < kPlLutSize; ++k) lut[k] = std::pow(10.0, -std::fabs(double(k)) / 10.0);
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_lut), lut.size() * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  CallIO cio;
+  cio.pl = d_pl16;
+  cio.lut = c->d_lut;
+  cio.col = c->d_col;
+  cio.seq = c->d_seq;
+  cio.gpp = gpp, cio.fpp = fpp, cio.fgt = fgt;
+  cio.n_seq = n_seq;
+  cio.magic_w = 0xFFFFFFFFu / uint32_t(3 * n_seq) + 1;
+  cio.magic_n = n_seq > 1 ? 0xFFFFFFFFu / uint32_t(n_seq) + 1 : 0;
+  if (!c->d_call_dev) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_call_dev), sizeof(CallIO)));
+  if (!c->call_dev_valid || std::memcmp(&cio, &c->call_dev_host, sizeof cio) != 0) {
+    // the argument block changes only when the caller's pointers do: written synchronously, after whatever of this stream
+    // may still read the old one
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    HIP_TRY(c, hipMemcpy(c->d_call_dev, &cio, sizeof cio, hipMemcpyHostToDevice));
+    c->call_dev_host = cio, c->call_dev_valid = true;
+  }
+  hipError_t e = hipSuccess;
+  const bool fused = launch_engine_fused(c, n_sites, d_lk, d_flags, status, d_pl16 != nullptr, c->d_call_dev, stream, &e);
+  if (fused) HIP_TRY(c, e);
+  if (!fused) {
+    const double *lk = d_lk;
+    if (d_pl16) {
+      HIP_TRY(c, launch_unpack_pl16(d_pl16, c->d_col, c->d_lut, N, n_seq, n_sites, c->dev_tmp[0], stream));
+      lk = c->dev_tmp[0];
+    }
+    HIP_TRY(c, launch_engine(c, n_sites, lk, d_flags, c->dev_tmp[1], c->dev_tmp[2], status, stream));
+    HIP_TRY(c, launch_phred_call(c->dev_tmp[1], c->dev_tmp[2], status, c->d_seq, N, n_seq, n_sites, gpp ? gpp : c->dev_tmp[3],
+                                 fpp ? fpp : c->dev_tmp[4], fgt ? fgt : c->dev_tmp_fgt, stream));
+  }
+  if (want_text)
+    HIP_TRY(c, launch_text_call(gpp ? gpp : c->dev_tmp[3], fpp ? fpp : c->dev_tmp[4], fgt ? fgt : c->dev_tmp_fgt, n_sites * n_seq, d_text, stream));
   return 0;
 }

@@ -556,7 +556,8 @@ const char kCallFlat[] = R"(
 typedef unsigned fs_v4u __attribute__((ext_vector_type(4)));
 #define RAW_V4 ((BT * NMEM * 6 + 15) / 16)  /* n_seq <= NMEM */
 #define RAW_K ((RAW_V4 + BT - 1) / BT)
-#define FS_LUT(x) ((x) < (unsigned)FS_LUT_LDS ? s_lut[x] : ((x) < 4096u ? lut_[x] : 0.0))
+/* the table value of a PL beyond the LDS part (rare: one real branch per item, nothing of it on the usual path) */
+#define FS_LUT_BIG(x, v) ((x) < (unsigned)FS_LUT_LDS ? (v) : ((x) < 4096u ? lut_[x] : 0.0))
 #define PL_FETCH(S0) { const FS_GLOBAL fs_v4u *r_ = (const FS_GLOBAL fs_v4u *)(call_g->pl + (S0) * call_g->n_seq * 3); \
   const int nv_ = (BT * call_g->n_seq * 6) / 16; int t_ = tid; FS_HIDE_LANE(t_); \
   _Pragma("unroll") for (int j_ = 0; j_ < RAW_K; ++j_) if (t_ + j_ * BT < nv_) praw[j_] = r_[t_ + j_ * BT]; }
@@ -571,8 +572,11 @@ typedef unsigned fs_v4u __attribute__((ext_vector_type(4)));
     if (c_ >= 0) { const unsigned short *q_ = raw_ + (s_ * n_seq + c_) * 3; a_[j_] = q_[0]; b_[j_] = q_[1]; d_[j_] = q_[2]; } } \
   LDS_BARRIER();  /* every lane holds its items: the rows (the raw pieces' place among them) may be written */ \
   _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) { const int it_ = t_ + j_ * BT, s_ = it_ / NMEM, i_ = it_ - s_ * NMEM; \
-    double v0_ = 1.0, v1_ = 1.0, v2_ = 1.0; \
-    if (!(a_[j_] == 0xFFFFu && b_[j_] == 0xFFFFu && d_[j_] == 0xFFFFu)) { v0_ = FS_LUT(a_[j_]); v1_ = FS_LUT(b_[j_]); v2_ = FS_LUT(d_[j_]); } \
+    const unsigned x0_ = a_[j_], x1_ = b_[j_], x2_ = d_[j_], top_ = FS_LUT_LDS - 1; \
+    const bool miss_ = (x0_ & x1_ & x2_) == 0xFFFFu;  /* 16-bit values: all three 0xFFFF */ \
+    double v0_ = s_lut[x0_ < top_ ? x0_ : top_], v1_ = s_lut[x1_ < top_ ? x1_ : top_], v2_ = s_lut[x2_ < top_ ? x2_ : top_]; \
+    if (miss_) { v0_ = 1.0; v1_ = 1.0; v2_ = 1.0; } \
+    else if ((x0_ | x1_ | x2_) >= (unsigned)FS_LUT_LDS) { FS_KEEP_BRANCH(); v0_ = FS_LUT_BIG(x0_, v0_); v1_ = FS_LUT_BIG(x1_, v1_); v2_ = FS_LUT_BIG(x2_, v2_); } \
     double *w_ = s_io + s_ * ROW + 3 * i_; w_[0] = v0_; w_[1] = v1_; w_[2] = v2_; } }
 )";
 
@@ -747,7 +751,10 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
   bool flat_pl = call_mode && entry == "famseq_elim" && bt % 8 == 0;  // (BT * n_seq * 6 bytes are whole 16-byte pieces)
   if (const char *e = std::getenv("FAMSEQ_CALL_FLAT")) flat_pl = flat_pl && std::atoi(e) != 0;
   int lut_lds = 1024;
-  if (const char *e = std::getenv("FAMSEQ_CALL_LUT_LDS")) lut_lds = std::max(1, std::atoi(e));  // tuning aid
+  if (const char *e = std::getenv("FAMSEQ_CALL_LUT_LDS")) {  // tuning aid; a power of two (the staging tests "any of the three beyond it" on their OR)
+    lut_lds = 1;
+    while (lut_lds * 2 <= std::min(4096, std::atoi(e))) lut_lds *= 2;
+  }
   if (flat_pl) s << "#define FS_LUT_LDS " << lut_lds << "\n" << kCallFlat;
 
   if (!regs_l)
@@ -792,7 +799,7 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
                   "  bool have_raw = false;\n"
 
                   : "")
-    << (phase_clock ? "  unsigned long long ph_last_ = 0, ph_acc_0 = 0, ph_acc_1 = 0, ph_acc_2 = 0, ph_acc_3 = 0, ph_acc_4 = 0, ph_acc_5 = 0, ph_acc_6 = 0;\n" : "")
+    << (phase_clock ? "  unsigned long long ph_last_ = 0, ph_acc_0 = 0, ph_acc_1 = 0, ph_acc_2 = 0, ph_acc_3 = 0, ph_acc_4 = 0, ph_acc_5 = 0, ph_acc_6 = 0, ph_acc_7 = 0;\n" : "")
     << (strided ? "  for (long ch = c_lo; ch < c_hi; ch += gridDim.x) {\n" : "  for (long ch = c_lo; ch < c_hi; ++ch) {\n")
     << "    const long site0 = ch * BT;\n"
     << "    const int ns = n_sites - site0 < BT ? (int)(n_sites - site0) : BT;\n"
@@ -849,10 +856,10 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
     s << (flat_pl ? "    have_raw = flat_ok && ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // the next chunk, if it is a whole one: its packed PLs land during the output phases\n"
                   "    if (have_raw) { PL_FETCH(site0 + BT); }\n" : "")
       << "    LDS_BARRIER();\n" << PH(3)
-      << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
-                    : "    STAGE_OUT(post_g);\n")
+      << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n" + PH(7) + "    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
+                    : std::string("    STAGE_OUT(post_g);\n"))
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
-      << PH(5) << (phase_clock ? "  }\n  if ((tid & 63) == 0 && call_g->phase_clk) { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); }\n}\n" : "  }\n}\n");
+      << PH(5) << (phase_clock ? "  }\n  if ((tid & 63) == 0 && call_g->phase_clk) { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); PH_FLUSH(7); }\n}\n" : "  }\n}\n");
   } else {
     // Outputs are staged through the same LDS rows as the input (coalesced 8 B/lane stores).
     // Writing each lane's row straight from registers was measured 20 % slower on MI355X
@@ -896,10 +903,10 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
       << (call_mode ? "      ROW_TO_CALL();  // the BN posterior as printed (FPP) and the genotype call\n" : "")
       << "    }\n"
       << "    LDS_BARRIER();\n" << PH(4)
-      << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
-                    : "    STAGE_OUT(post_g);\n")
+      << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n" + PH(7) + "    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
+                    : std::string("    STAGE_OUT(post_g);\n"))
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
-      << PH(5) << (phase_clock ? "  }\n  if ((tid & 63) == 0 && call_g->phase_clk) { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); }\n}\n" : "  }\n}\n");
+      << PH(5) << (phase_clock ? "  }\n  if ((tid & 63) == 0 && call_g->phase_clk) { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); PH_FLUSH(7); }\n}\n" : "  }\n}\n");
   }
   return s.str();
 }

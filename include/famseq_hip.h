@@ -239,6 +239,15 @@ int famseq_bn_call_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, con
 int famseq_bn_call_text_batch(famseq_ctx *ctx, int64_t n_sites, const double *lk, const uint16_t *pl16,
                               const uint8_t *flags, const int32_t *seq_members, int32_t n_seq, char *text, uint8_t *status);
 
+/* The call path on DEVICE buffers already resident on ctx's device: enqueues on `stream` (a hipStream_t; NULL = the default stream)
+ * and returns without synchronising; nothing crosses the host link.  Exactly one of d_lk / d_pl16; seq_members is a HOST array
+ * (uploaded when it changes); any of d_gpp / d_fpp / d_fgt / d_status / d_text may be NULL (d_text: 16-byte aligned,
+ * [n_sites][n_seq][FAMSEQ_TEXT_STRIDE]).  The same kernels as famseq_bn_call_batch / famseq_bn_call_text_batch; batches they do not
+ * serve fused go through scratch rows this context keeps (grown on demand). */
+int famseq_bn_call_batch_device(famseq_ctx *ctx, int64_t n_sites, const double *d_lk, const uint16_t *d_pl16,
+                                const uint8_t *d_flags, const int32_t *seq_members, int32_t n_seq, double *d_gpp, double *d_fpp,
+                                int8_t *d_fgt, uint8_t *d_status, char *d_text, void *stream);
+
 /* Diagnostic / test aid: the device formatter alone.  values[n] (host) -> out[n][16] (host): the characters of each
  * value as the text kernel prints a GPP / FPP number from byte 0, their count in byte 15; "nan" for anything outside
  * the formatter's domain, 0 and [1e-16, 999999.5). */

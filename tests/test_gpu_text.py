@@ -100,3 +100,45 @@ def test_text_from_packed_pls_at_size():
     assert ln.min() >= 16 and ln.max() <= 76
     flat = text.reshape(-1, fs.TEXT_STRIDE)
     assert np.all(flat[np.arange(len(flat)), ln.ravel() - 1] == ord("\t"))
+
+
+@pytest.mark.parametrize("label,opts", ENGINES, ids=[e[0] for e in ENGINES])
+def test_device_resident_call_path_gives_the_host_entry_bits(label, opts):
+    """famseq_bn_call_batch_device on resident buffers (packed PLs and fp64 rows; with every output, and with the text alone)
+    against famseq_bn_call_batch / famseq_bn_call_text_batch on host buffers: the same kernels, the same bits."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ped = fs.synthetic_pedigree("ped10")
+    s = 5000 if opts.get("enum_impl") == 0 else 40000
+    mo, fa = ped.relations()
+    pl, known, _ = fs.synth.gen_sites(mo, fa, s, seed=fs.synth.SEED_BASE + 2)
+    pl16 = pl.astype(np.uint16)
+    pl16[5, 3] = 0xFFFF   # a missing sample
+    pl16[7, 2, 1] = 3300  # beyond where pow(10, -k / 10) is 0 in double
+    pl16[9, 1, 2] = 1500  # beyond the part of the table the sum-product form keeps in LDS
+    flags = known.astype(np.uint8)
+    seq = np.arange(ped.n, dtype=np.int32)[::-1].copy()
+    ctx = fs.Context(fs.make_model(ped), **opts)
+    gpp, fpp, fgt, st = ctx.bn_call_batch(seq, pl16=pl16, flags=flags)
+    text, _ = ctx.bn_call_text_batch(seq, pl16=pl16, flags=flags)
+    d_pl, d_fl = torch.from_numpy(pl16.view(np.int16)).to(dev), torch.from_numpy(flags).to(dev)
+    d_gpp, d_fpp = torch.empty((s, ped.n, 3), dtype=torch.float64, device=dev), torch.empty((s, ped.n, 3), dtype=torch.float64, device=dev)
+    d_fgt, d_st = torch.empty((s, ped.n), dtype=torch.int8, device=dev), torch.empty(s, dtype=torch.uint8, device=dev)
+    d_text = torch.zeros((s, ped.n, fs.TEXT_STRIDE), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.bn_call_batch_device(s, seq, d_pl16=d_pl.data_ptr(), d_flags=d_fl.data_ptr(), d_gpp=d_gpp.data_ptr(), d_fpp=d_fpp.data_ptr(),
+                             d_fgt=d_fgt.data_ptr(), d_status=d_st.data_ptr(), d_text=d_text.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_st.cpu().numpy(), st) and np.array_equal(d_fgt.cpu().numpy(), fgt)
+    assert np.array_equal(d_gpp.cpu().numpy(), gpp, equal_nan=True) and np.array_equal(d_fpp.cpu().numpy(), fpp, equal_nan=True)
+    assert np.array_equal(d_text.cpu().numpy(), text)
+    # the text alone (the numbers go through this context's scratch), from fp64 rows this time
+    lk = fs.synth.pl_to_lk(pl)[:2000]
+    t2, st2 = ctx.bn_call_text_batch(seq, lk=lk, flags=flags[:2000])
+    d_lk = torch.from_numpy(np.ascontiguousarray(lk)).to(dev)
+    d_text.zero_()
+    ctx.bn_call_batch_device(2000, seq, d_lk=d_lk.data_ptr(), d_flags=d_fl.data_ptr(), d_text=d_text.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_text[:2000].cpu().numpy(), t2)
+    ctx.close()
