@@ -33,7 +33,7 @@ using namespace famseq;
 struct CallIO {  // = struct fs_call_args of the generated source (elim_codegen.cpp kCallHelpers)
   const uint16_t *pl = nullptr;
   const double *lut = nullptr;
-  const int32_t *col = nullptr, *seq = nullptr;
+  const int32_t *col = nullptr, *slot = nullptr;
   double *gpp = nullptr, *fpp = nullptr;
   int8_t *fgt = nullptr;
   int32_t n_seq = 0;
@@ -104,7 +104,7 @@ struct famseq_ctx {
   int8_t *d_fgt[kSlots] = {};
   char *d_text[kSlots] = {};  // text records of the called outputs (famseq_bn_call_text_batch)
   double *d_lut = nullptr;
-  int32_t *d_seq = nullptr, *d_col = nullptr;
+  int32_t *d_seq = nullptr, *d_col = nullptr, *d_slot = nullptr;  // column -> member; member -> column or -1; member -> output slot
   CallIO *d_call[kSlots] = {};  // the generated kernels' call-path arguments, one per slot
   unsigned long long *d_phase = nullptr;  // FAMSEQ_PHASE_CLOCK: kPhases counters
   // device-resident call path (famseq_bn_call_batch_device): its own argument block, what it holds, and scratch rows for
@@ -573,6 +573,7 @@ extern "C" void famseq_destroy(famseq_ctx *c) {
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_seq) (void)hipFree(c->d_seq);
     if (c->d_col) (void)hipFree(c->d_col);
+    if (c->d_slot) (void)hipFree(c->d_slot);
     for (int s = 0; s < famseq_ctx::kSlots; ++s)
       if (c->d_call[s]) (void)hipFree(c->d_call[s]);
     if (c->d_call_dev) (void)hipFree(c->d_call_dev);
@@ -911,6 +912,12 @@ int set_sequenced(famseq_ctx *c, const int32_t *seq, int n_seq) {
   if (c->d_seq && v == c->seq_members) return 0;
   if (!c->d_seq) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_seq), c->model.n_members * sizeof(int32_t)));
   if (!c->d_col) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_col), c->model.n_members * sizeof(int32_t)));
+  if (!c->d_slot) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->d_slot), c->model.n_members * sizeof(int32_t)));
+  // where a member's printed values go in the call-path kernels' output rows: its column; members without one fill the slots behind
+  std::vector<int32_t> slot(col);
+  for (int p = 0, next = n_seq; p < c->model.n_members; ++p)
+    if (slot[p] < 0) slot[p] = next++;
+  HIP_TRY(c, hipMemcpy(c->d_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   if (n_seq) HIP_TRY(c, hipMemcpy(c->d_seq, v.data(), n_seq * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_col, col.data(), col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   c->seq_members = v;
@@ -976,7 +983,7 @@ int run_host(famseq_ctx *c, int64_t n_sites, const HostIO &io, int n_seq) {
       cio.pl = io.pl16 ? c->d_pl[s] : nullptr;
       cio.lut = c->d_lut;
       cio.col = c->d_col;
-      cio.seq = c->d_seq;
+      cio.slot = c->d_slot;
       cio.gpp = io.gpp || io.text ? c->d_gpp[s] : nullptr;
       cio.fpp = io.fpp || io.text ? c->d_fpp[s] : nullptr;
       cio.fgt = io.fgt || io.text ? c->d_fgt[s] : nullptr;
@@ -1261,7 +1268,7 @@ extern "C" int famseq_bn_call_batch_device(famseq_ctx *c, int64_t n_sites, const
   cio.pl = d_pl16;
   cio.lut = c->d_lut;
   cio.col = c->d_col;
-  cio.seq = c->d_seq;
+  cio.slot = c->d_slot;
   cio.gpp = gpp, cio.fpp = fpp, cio.fgt = fgt;
   cio.n_seq = n_seq;
   cio.magic_w = 0xFFFFFFFFu / uint32_t(3 * n_seq) + 1;

@@ -461,7 +461,7 @@ typedef double fs_v2d __attribute__((ext_vector_type(2)));
 struct fs_call_args {
   const FS_GLOBAL unsigned short *pl;  // [n_sites][n_seq][3] packed PLs, or null: fp64 likelihood rows come in as usual
   const FS_GLOBAL double *lut;         // pow(10, -k / 10), k < 4096
-  const FS_GLOBAL int *col, *seq;      // member -> VCF column or -1; VCF column -> member
+  const FS_GLOBAL int *col, *slot;     // member -> VCF column or -1; member -> its slot of the output row (its column, or one behind the columns)
   FS_GLOBAL double *gpp, *fpp;         // [n_sites][n_seq][3], either may be null
   FS_GLOBAL signed char *fgt;          // [n_sites][n_seq] or null
   int n_seq;
@@ -480,67 +480,76 @@ struct fs_call_args {
   const FS_GLOBAL unsigned short *p_ = call_g->pl + site0 * n_seq * 3; \
   if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < NMEM; ++j_) PL_ITEM(tid + j_ * BT) } \
   else { for (int it_ = tid; it_ < ns * NMEM; it_ += BT) PL_ITEM(it_) } }
-// The lane's row holds probabilities (single or BN posterior, NaN where the site failed): turn it in place
-// into what is printed, fabs(-10 log10 p), and note the arg-max genotype of every member (strict '<' from
-// -1: ties to the lower genotype, NaN rows give -1).  3 N independent logarithms per lane — independent for the
-// scheduler only inside one basic block: with fs_phred's own branch per logarithm (the special values) each one was a
-// block of its own, table read -> wait -> nine dependent FMAs, thirty times in a row.  Two members at a time, the
-// six logarithms branch-free and ONE branch behind them for the rare row that holds a zero or a NaN.
+// What is printed, formed from REGISTERS and laid down in OUTPUT order.  V[3 p + g] holds member p's probabilities (single or
+// BN posterior, NaN where the site failed); member p's printed values fabs(-10 log10 p) go to slot slot_r_[p] of the lane's row —
+// its VCF column if it has one, a slot behind the columns otherwise — and its arg-max genotype (strict '<' from -1: ties to the
+// lower genotype, NaN rows give -1) to the same slot of the byte table.  The rows then ARE the output, site by site: the
+// stage-out is a copy (rounds 1-3 kept member order in the row and gathered on the way out: an index read, a value read and
+// twenty integer instructions per element, 36 % of the kernel's wave cycles at ten members).  Reading from registers also makes
+// the permutation safe (nothing of the row is read while it is rewritten) and spares the row a round trip.
+// 3 N independent logarithms per lane — independent for the scheduler only inside one basic block: with fs_phred's own branch
+// per logarithm (the special values) each one was a block of its own, table read -> wait -> nine dependent FMAs, thirty times in
+// a row.  Two members at a time, the six logarithms branch-free and ONE branch behind them for the rare row with a zero or a NaN.
 #define ARGMAX3(a0_, a1_, a2_, slot_) { signed char pk_ = -1; double bs_ = -1; \
     if (bs_ < a0_) { bs_ = a0_; pk_ = 0; } if (bs_ < a1_) { bs_ = a1_; pk_ = 1; } if (bs_ < a2_) { bs_ = a2_; pk_ = 2; } \
     s_fgt[tid * NMEM + (slot_)] = pk_; }
-#define ROW_TO_CALL() { _Pragma("unroll") for (int p_ = 0; p_ + 1 < (FS_PHRED_GROUP == 2 ? NMEM : 0); p_ += 2) { \
-    const double d0_ = row[3 * p_], d1_ = row[3 * p_ + 1], d2_ = row[3 * p_ + 2], d3_ = row[3 * p_ + 3], d4_ = row[3 * p_ + 4], d5_ = row[3 * p_ + 5]; \
-    ARGMAX3(d0_, d1_, d2_, p_) ARGMAX3(d3_, d4_, d5_, p_ + 1) \
+#define PUT_CALL(V) { _Pragma("unroll") for (int p_ = 0; p_ + 1 < (FS_PHRED_GROUP == 2 ? NMEM : 0); p_ += 2) { \
+    const int o0_ = slot_r_[p_], o1_ = slot_r_[p_ + 1]; \
+    const double d0_ = V[3 * p_], d1_ = V[3 * p_ + 1], d2_ = V[3 * p_ + 2], d3_ = V[3 * p_ + 3], d4_ = V[3 * p_ + 4], d5_ = V[3 * p_ + 5]; \
+    ARGMAX3(d0_, d1_, d2_, o0_) ARGMAX3(d3_, d4_, d5_, o1_) \
     double q0_ = fs_phred_fast(d0_, s_lt), q1_ = fs_phred_fast(d1_, s_lt), q2_ = fs_phred_fast(d2_, s_lt); \
     double q3_ = fs_phred_fast(d3_, s_lt), q4_ = fs_phred_fast(d4_, s_lt), q5_ = fs_phred_fast(d5_, s_lt); \
     if (!(FS_IS_POS_FINITE(d0_) & FS_IS_POS_FINITE(d1_) & FS_IS_POS_FINITE(d2_) & FS_IS_POS_FINITE(d3_) & FS_IS_POS_FINITE(d4_) & FS_IS_POS_FINITE(d5_))) { \
       FS_KEEP_BRANCH(); q0_ = fs_phred_fix(d0_, q0_); q1_ = fs_phred_fix(d1_, q1_); q2_ = fs_phred_fix(d2_, q2_); \
       q3_ = fs_phred_fix(d3_, q3_); q4_ = fs_phred_fix(d4_, q4_); q5_ = fs_phred_fix(d5_, q5_); } \
-    row[3 * p_] = q0_; row[3 * p_ + 1] = q1_; row[3 * p_ + 2] = q2_; row[3 * p_ + 3] = q3_; row[3 * p_ + 4] = q4_; row[3 * p_ + 5] = q5_; } \
-  _Pragma("unroll") for (int p_ = (FS_PHRED_GROUP == 2 ? (NMEM & ~1) : 0); p_ < NMEM; ++p_) { const double d0_ = row[3 * p_], d1_ = row[3 * p_ + 1], d2_ = row[3 * p_ + 2]; \
-    ARGMAX3(d0_, d1_, d2_, p_) \
+    double *w0_ = row + 3 * o0_, *w1_ = row + 3 * o1_; \
+    w0_[0] = q0_; w0_[1] = q1_; w0_[2] = q2_; w1_[0] = q3_; w1_[1] = q4_; w1_[2] = q5_; } \
+  _Pragma("unroll") for (int p_ = (FS_PHRED_GROUP == 2 ? (NMEM & ~1) : 0); p_ < NMEM; ++p_) { const int o0_ = slot_r_[p_]; \
+    const double d0_ = V[3 * p_], d1_ = V[3 * p_ + 1], d2_ = V[3 * p_ + 2]; \
+    ARGMAX3(d0_, d1_, d2_, o0_) \
     double q0_ = fs_phred_fast(d0_, s_lt), q1_ = fs_phred_fast(d1_, s_lt), q2_ = fs_phred_fast(d2_, s_lt); \
     if (!(FS_IS_POS_FINITE(d0_) & FS_IS_POS_FINITE(d1_) & FS_IS_POS_FINITE(d2_))) { \
       FS_KEEP_BRANCH(); q0_ = fs_phred_fix(d0_, q0_); q1_ = fs_phred_fix(d1_, q1_); q2_ = fs_phred_fix(d2_, q2_); } \
-    row[3 * p_] = q0_; row[3 * p_ + 1] = q1_; row[3 * p_ + 2] = q2_; } }
-// rows -> [site][VCF column][genotype], coalesced; FGT likewise from the byte table
-#define CALL_ELEM(e_) { const int s_ = (int)FS_UMULHI((unsigned)(e_), mg_), r_ = (e_) - s_ * w_, k_ = (r_ * 171) >> 9; \
-    __builtin_nontemporal_store(s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)], g_ + (e_)); }
+    double *w0_ = row + 3 * o0_; w0_[0] = q0_; w0_[1] = q1_; w0_[2] = q2_; } }
+// ... and from a row that holds them in member order (the registers-first shells, whose body writes its marginals there): every
+// value is read before the first is written
+#define ROW_TO_CALL() { double u_[W3]; _Pragma("unroll") for (int k_ = 0; k_ < W3; ++k_) u_[k_] = row[k_]; PUT_CALL(u_) }
+// rows -> [site][VCF column][genotype]: element e = s w + r of the chunk sits at s ROW + r (w = 3 n_seq <= ROW); FGT likewise
+// from the byte table (s NMEM + k)
+#define OUT_ELEM(e_) { const int s_ = (int)FS_UMULHI((unsigned)(e_), mg_), r_ = (e_) - s_ * w_; \
+    __builtin_nontemporal_store(s_io[s_ * ROW + r_], g_ + (e_)); }
 // two neighbouring elements per lane and store (16 B; the second may be the next site's first)
-#define CALL_PAIR(p2_) { const int e_ = 2 * (p2_), s_ = (int)FS_UMULHI((unsigned)e_, mg_), r_ = e_ - s_ * w_, k_ = (r_ * 171) >> 9; \
-    const int w1_ = r_ + 1 == w_, s1_ = s_ + w1_, r1_ = w1_ ? 0 : r_ + 1, k1_ = (r1_ * 171) >> 9; \
-    fs_v2d v_; v_.x = s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)]; v_.y = s_io[s1_ * ROW + 3 * s_seq[k1_] + (r1_ - 3 * k1_)]; \
+#define OUT_PAIR(p2_) { const int e_ = 2 * (p2_), s_ = (int)FS_UMULHI((unsigned)e_, mg_), r_ = e_ - s_ * w_, a_ = s_ * ROW + r_; \
+    fs_v2d v_; v_.x = s_io[a_]; v_.y = s_io[r_ + 1 == w_ ? a_ + 1 + (ROW - w_) : a_ + 1]; \
     __builtin_nontemporal_store(v_, (FS_GLOBAL fs_v2d *)(g_ + e_)); }
 // (NSEQ_CT: the pedigree's number of sequenced members, what n_seq is unless the caller names another set of columns.  With the
 // row width a constant the walk over a whole chunk has no bound to test per step — each test was a branch, each branch a basic
-// block of its own: index read -> wait -> value read -> wait -> store, fifteen times in a row — and its loads go out together.)
-// FS_CT_OUT = 2: the walk in groups of four steps, fenced one from the next — four steps' loads in flight together instead of all
-// fifteen: a dozen registers instead of sixty (at the 256-register cap of two waves per SIMD all fifteen spill)
+// block of its own — and its loads go out together.)
+// FS_CT_OUT = 2: the walk in groups of four steps, fenced one from the next (fewer loads in flight, fewer registers).
 // The walks' indices depend on the lane only.  Left alone, hipcc computes them once, before the chunk loop — free while registers
-// are (small pedigrees: 0.067 against 0.088 ms per 1 M trios), sixty spilled registers at the 256 cap otherwise.  FS_OPAQUE_LANE
-// (from seven members on; the enumeration's form from five) makes the lane id opaque at each walk, so that they are formed again per chunk.
+// are (small pedigrees), sixty spilled registers at the 256 cap otherwise.  FS_OPAQUE_LANE (from seven members on; the
+// enumeration's form from five) makes the lane id opaque at each walk, so that they are formed again per chunk.
 #define FS_HIDE_LANE(t_) if (FS_OPAQUE_LANE) asm volatile("" : "+v"(t_))
 #define FS_OUT_FENCE(j_) if (FS_CT_OUT == 2 && ((j_) & 3) == 3) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#define CALL_PAIR_CT(p2_) { const int e_ = 2 * (p2_), s_ = e_ / (3 * NSEQ_CT), r_ = e_ - s_ * (3 * NSEQ_CT), k_ = (r_ * 171) >> 9; \
-    const int w1_ = r_ + 1 == 3 * NSEQ_CT, s1_ = s_ + w1_, r1_ = w1_ ? 0 : r_ + 1, k1_ = (r1_ * 171) >> 9; \
-    fs_v2d v_; v_.x = s_io[s_ * ROW + 3 * s_seq[k_] + (r_ - 3 * k_)]; v_.y = s_io[s1_ * ROW + 3 * s_seq[k1_] + (r1_ - 3 * k1_)]; \
+#define WOUT_CT (3 * NSEQ_CT)
+#define OUT_PAIR_CT(p2_) { const int e_ = 2 * (p2_), s_ = e_ / WOUT_CT, r_ = e_ - s_ * WOUT_CT, a_ = s_ * ROW + r_; \
+    fs_v2d v_; v_.x = s_io[a_]; v_.y = s_io[(WOUT_CT & 1) && r_ + 1 == WOUT_CT ? a_ + 1 + (ROW - WOUT_CT) : a_ + 1]; \
     __builtin_nontemporal_store(v_, (FS_GLOBAL fs_v2d *)(g_ + e_)); }
 #define STAGE_OUT_CALL(Gp) { const int w_ = 3 * call_g->n_seq; const unsigned mg_ = call_g->magic_w; FS_GLOBAL double *g_ = (Gp) + site0 * w_; \
-  if (FS_CT_OUT && whole && (BT & 1) == 0 && ((unsigned long)g_ & 15) == 0 && w_ == 3 * NSEQ_CT) { \
-    int t_ = tid; FS_HIDE_LANE(t_);  /* opaque: the walk's indices depend on the lane only, and hipcc would keep all of them in registers (spilled) across the chunk loop */ \
-    _Pragma("unroll") for (int j_ = 0; j_ < (3 * NSEQ_CT) / 2; ++j_) { CALL_PAIR_CT(t_ + j_ * BT) FS_OUT_FENCE(j_) } \
-    if ((3 * NSEQ_CT) & 1) { if (t_ < BT / 2) CALL_PAIR_CT(t_ + (3 * NSEQ_CT) / 2 * BT) } } \
+  if (FS_CT_OUT && whole && (BT & 1) == 0 && ((unsigned long)g_ & 15) == 0 && w_ == WOUT_CT) { \
+    int t_ = tid; FS_HIDE_LANE(t_); \
+    _Pragma("unroll") for (int j_ = 0; j_ < WOUT_CT / 2; ++j_) { OUT_PAIR_CT(t_ + j_ * BT) FS_OUT_FENCE(j_) } \
+    if (WOUT_CT & 1) { if (t_ < BT / 2) OUT_PAIR_CT(t_ + WOUT_CT / 2 * BT) } } \
   else if (whole && (BT & 1) == 0 && ((unsigned long)g_ & 15) == 0) { const int half_ = BT / 2 * w_; \
-    _Pragma("unroll") for (int j_ = 0; j_ < (3 * NMEM + 1) / 2; ++j_) if (tid + j_ * BT < half_) CALL_PAIR(tid + j_ * BT) } \
-  else if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < 3 * NMEM; ++j_) if (j_ < w_) CALL_ELEM(tid + j_ * BT) } \
-  else { for (int e = tid; e < ns * w_; e += BT) CALL_ELEM(e) } }
+    _Pragma("unroll") for (int j_ = 0; j_ < (3 * NMEM + 1) / 2; ++j_) if (tid + j_ * BT < half_) OUT_PAIR(tid + j_ * BT) } \
+  else if (whole) { _Pragma("unroll") for (int j_ = 0; j_ < 3 * NMEM; ++j_) if (j_ < w_) OUT_ELEM(tid + j_ * BT) } \
+  else { for (int e = tid; e < ns * w_; e += BT) OUT_ELEM(e) } }
 #define STAGE_FGT(Gp) { const int n_seq = call_g->n_seq; const unsigned mg_ = call_g->magic_n; FS_GLOBAL signed char *g_ = (Gp) + site0 * n_seq; \
   if (FS_CT_OUT && whole && n_seq == NSEQ_CT) { int t_ = tid; FS_HIDE_LANE(t_); \
     _Pragma("unroll") for (int j_ = 0; j_ < NSEQ_CT; ++j_) { const int it_ = t_ + j_ * BT, s_ = it_ / NSEQ_CT, k_ = it_ - s_ * NSEQ_CT; \
-    g_[it_] = s_fgt[s_ * NMEM + s_seq[k_]]; FS_OUT_FENCE(j_) } } \
+    g_[it_] = s_fgt[s_ * NMEM + k_]; FS_OUT_FENCE(j_) } } \
   else for (int it_ = tid; it_ < ns * n_seq; it_ += BT) { const int s_ = mg_ ? (int)FS_UMULHI((unsigned)it_, mg_) : it_, k_ = it_ - s_ * n_seq; \
-    g_[it_] = s_fgt[s_ * NMEM + s_seq[k_]]; } }
+    g_[it_] = s_fgt[s_ * NMEM + k_]; } }
 )");
 // The sum-product kernel's call-path form spent 44 % of its wave cycles in STAGE_IN_PL (FAMSEQ_PHASE_CLOCK, ten members): 30 two-byte
 // loads per lane, then 30 table look-ups that each touch up to 64 cache lines, both waited for by every wave of the workgroup
@@ -599,7 +608,7 @@ const char kCallArgs[] = ", const struct fs_call_args *__restrict__ call_g";
 // Statements of the single posterior (family.cpp:1426-1445) and of the shortcut vote (:767-789), the
 // same as in bn_kernel.hip; they read l<p>_<g> and tcf[], set single_fail / full, and (store) write
 // the normalised rows to row[].  Shared by every generated shell.
-std::string single_posterior_statements(const Model &m, bool flags_pass, bool store, bool fence_single) {
+std::string single_posterior_statements(const Model &m, bool flags_pass, bool store, bool fence_single, const char *dst) {
   std::ostringstream s;
   const int N = m.n_members;
   for (int p = 0; p < N; ++p) {
@@ -610,7 +619,7 @@ std::string single_posterior_statements(const Model &m, bool flags_pass, bool st
     if (flags_pass) s << " if (s <= 0) single_fail = true;";
     s << "\n";
     if (store)
-      s << "      row[" << 3 * p << "] = p0 / s; row[" << 3 * p + 1 << "] = p1 / s; row[" << 3 * p + 2 << "] = p2 / s;\n";
+      s << "      " << dst << "[" << 3 * p << "] = p0 / s; " << dst << "[" << 3 * p + 1 << "] = p1 / s; " << dst << "[" << 3 * p + 2 << "] = p2 / s;\n";
     if (flags_pass && m.sequenced[p])
       s << "      double big = 0; if (big < a0) big = a0; if (big < a1) big = a1; if (big < a2) big = a2;\n"
         << "      const double sum = (a0 + a1) + a2; big = big / sum; if (big < lc) full = true;\n";
@@ -786,11 +795,16 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
     << "  const bool v16 = (((unsigned long)lk_g | (unsigned long)post_g | (unsigned long)single_g) & 15) == 0;\n"
     << "  bool have_pre = false;\n"
     << (call_mode ? "  const bool packed_in = call_g->pl != nullptr;  // fed with packed PLs (else fp64 rows)\n"
-                    "  __shared__ int s_col[NMEM], s_seq[NMEM];  // member -> VCF column or -1; VCF column -> member\n"
+                    "  __shared__ int s_col[NMEM];  // member -> VCF column or -1\n"
+                    // member -> slot of the output row, the same for every lane and chunk.  Small pedigrees keep them in scalar registers
+                    // (per use an LDS read is a latency the trio's short phases feel: 0.063 against 0.082 ms per 1 M sites); from seven
+                    // members on they live in LDS (ten more live SGPRs at ten members: every variant spills, 0.253 against 0.213 ms)
+                    "#if NMEM < 7\n  int slot_r_[NMEM];\n#pragma unroll\n  for (int i = 0; i < NMEM; ++i) slot_r_[i] = call_g->slot[i];\n"
+                    "#else\n  __shared__ int slot_r_[NMEM];\n  for (int i = tid; i < NMEM; i += BT) slot_r_[i] = call_g->slot[i];\n#endif\n"
                     "  __shared__ signed char s_fgt[BT * NMEM];  // arg-max genotype of every member of every site of the chunk\n"
                     "  __shared__ __attribute__((aligned(16))) double s_lt[258];  // fs_phred's table: one 16-byte LDS read per logarithm\n"
                     "  for (int i = tid; i < 258; i += BT) s_lt[i] = fs_logtab[i];\n"
-                    "  for (int i = tid; i < NMEM; i += BT) { s_col[i] = call_g->col[i]; s_seq[i] = i < call_g->n_seq ? call_g->seq[i] : 0; }\n"
+                    "  for (int i = tid; i < NMEM; i += BT) s_col[i] = call_g->col[i];\n"
                   : "")
     << (flat_pl ? "  __shared__ double s_lut[FS_LUT_LDS];  // pow(10, -k / 10), k < FS_LUT_LDS\n"
                   "  if (packed_in) for (int i = tid; i < FS_LUT_LDS; i += BT) s_lut[i] = call_g->lut[i];\n"
@@ -821,7 +835,9 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
     << "    const int fl = (tid < ns && flags_g) ? (flags_g[site0 + tid] & 3) : 0;\n"
     << "    const double *tcf = s_tc + fl * 108;\n"
     << "    bool single_fail = false, full = false, bn_fail = false;\n";
-  auto single_pass = [&](bool flags_pass, bool store) { s << single_posterior_statements(m, flags_pass, store, fence_single); };
+  auto single_pass = [&](bool flags_pass, bool store, const char *dst = "row") {
+    s << single_posterior_statements(m, flags_pass, store, fence_single, dst);
+  };
   if (regs_l) {
     for (int p = 0; p < N; ++p)
       for (int gt = 0; gt < 3; ++gt) s << "    const double l" << p << "_" << gt << " = row[" << 3 * p + gt << "];\n";
@@ -892,15 +908,23 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
       << "    if (have_pre) { PREFETCH(lk_g); }\n";
     s << PH(3) << (flat_pl ? "    have_raw = flat_ok && ch + 1 < c_hi && site0 + 2 * BT <= n_sites;  // the next chunk, if it is a whole one: its packed PLs land during the output phases\n"
                   "    if (have_raw) { PL_FETCH(site0 + BT); }\n" : "");
-    single_pass(false, true);  // now the single posterior may take the row over
-    s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n"
-      << (call_mode ? "    ROW_TO_CALL();  // the single posterior as printed (GPP) and its arg-max (FGT of shortcut sites)\n" : "")
-      << "    LDS_BARRIER();\n" << PH(1)
+    if (call_mode) {
+      // the call path: the single posterior stays in registers, and what is printed of it (GPP; the arg-max is the FGT of
+      // shortcut sites) goes to the row in output order — every likelihood has been read by then
+      s << "    double u_[W3];\n";
+      single_pass(false, true, "u_");
+      s << "    if (single_fail) for (int k = 0; k < W3; ++k) u_[k] = kNaN;\n    PUT_CALL(u_);\n";
+    } else {
+      single_pass(false, true);  // now the single posterior may take the row over
+      s << "    if (single_fail) for (int k = 0; k < W3; ++k) row[k] = kNaN;\n";
+    }
+    s << "    LDS_BARRIER();\n" << PH(1)
       << (call_mode ? "    if (call_g->gpp) { STAGE_OUT_CALL(call_g->gpp); }\n" : "    if (single_g) { STAGE_OUT(single_g); }\n")
       << "    LDS_BARRIER();  // single rows are stored; sites that ran the full computation overwrite theirs\n" << PH(2)
       << "    if (full && !single_fail) {\n"
-      << "#pragma unroll\n      for (int k = 0; k < W3; ++k) row[k] = bn_fail ? kNaN : q[k];\n"
-      << (call_mode ? "      ROW_TO_CALL();  // the BN posterior as printed (FPP) and the genotype call\n" : "")
+      << (call_mode ? "      if (bn_fail) for (int k = 0; k < W3; ++k) q[k] = kNaN;\n"
+                      "      PUT_CALL(q);  // the BN posterior as printed (FPP) and the genotype call, straight from the registers\n"
+                    : "#pragma unroll\n      for (int k = 0; k < W3; ++k) row[k] = bn_fail ? kNaN : q[k];\n")
       << "    }\n"
       << "    LDS_BARRIER();\n" << PH(4)
       << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n" + PH(7) + "    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"

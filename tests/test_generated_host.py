@@ -307,8 +307,20 @@ def test_lanes_per_site_mode_matches_the_fixtures(case, d, tmp_path, monkeypatch
     assert np.all(np.isnan(post[~ok]))
 
 
+def output_slots(col, n, k):
+    """member -> slot of the call-path kernels' output row: its VCF column, or — no column — one behind the k columns
+    (what capi.cpp set_sequenced uploads)."""
+    slot = np.array(col[:n], np.int32)
+    nxt = k
+    for p in range(n):
+        if slot[p] < 0:
+            slot[p] = nxt
+            nxt += 1
+    return slot
+
+
 class CallArgs(C.Structure):  # struct fs_call_args of the generated source
-    _fields_ = [("pl", C.c_void_p), ("lut", C.c_void_p), ("col", C.c_void_p), ("seq", C.c_void_p), ("gpp", C.c_void_p),
+    _fields_ = [("pl", C.c_void_p), ("lut", C.c_void_p), ("col", C.c_void_p), ("slot", C.c_void_p), ("gpp", C.c_void_p),
                 ("fpp", C.c_void_p), ("fgt", C.c_void_p), ("n_seq", C.c_int32), ("magic_w", C.c_uint32), ("magic_n", C.c_uint32)]
 
 
@@ -344,6 +356,7 @@ def test_call_path_forms_match_the_fixtures(case, kind, tmp_path, monkeypatch):
     k = len(seq)
     col = np.full(20, -1, np.int32)
     col[seq] = np.arange(k)
+    slot = output_slots(col, n, k)
     lut = np.array([math.pow(10.0, -i / 10.0) for i in range(4096)])
     tc = np.ascontiguousarray(factor_tables(model))
 
@@ -351,7 +364,7 @@ def test_call_path_forms_match_the_fixtures(case, kind, tmp_path, monkeypatch):
         S = len(flags)
         gpp, fpp = np.full((S, k, 3), -7.0), np.full((S, k, 3), -7.0)
         fgt, st = np.full((S, k), 9, np.int8), np.full(S, 77, np.uint8)
-        a = CallArgs(None if pl is None else pl.ctypes.data, lut.ctypes.data, col.ctypes.data, seq.ctypes.data, gpp.ctypes.data,
+        a = CallArgs(None if pl is None else pl.ctypes.data, lut.ctypes.data, col.ctypes.data, slot.ctypes.data, gpp.ctypes.data,
                      fpp.ctypes.data, fgt.ctypes.data, k, 0xFFFFFFFF // (3 * k) + 1, 0xFFFFFFFF // k + 1)
         keep = misaligned(lk.shape) if lk is not None else None
         if lk is not None:
@@ -490,6 +503,7 @@ def test_call_path_forms_as_whole_workgroups(seed, tmp_path, monkeypatch):
     k = len(seq)
     col = np.full(20, -1, np.int32)
     col[seq] = np.arange(k)
+    slot = output_slots(col, n, k)
     lut = np.array([math.pow(10.0, -i / 10.0) for i in range(4096)])
     tc = np.ascontiguousarray(factor_tables(model))
     probe = fs.Context(model, device=-1)
@@ -513,7 +527,7 @@ def test_call_path_forms_as_whole_workgroups(seed, tmp_path, monkeypatch):
             def run(lk_in=None, pl_in=None):
                 gpp, fpp = np.full((S, k, 3), -7.0), np.full((S, k, 3), -7.0)
                 fgt, st = np.full((S, k), 9, np.int8), np.full(S, 77, np.uint8)
-                a = CallArgs(None if pl_in is None else pl_in.ctypes.data, lut.ctypes.data, col.ctypes.data, seq.ctypes.data,
+                a = CallArgs(None if pl_in is None else pl_in.ctypes.data, lut.ctypes.data, col.ctypes.data, slot.ctypes.data,
                              gpp.ctypes.data, fpp.ctypes.data, fgt.ctypes.data, k, 0xFFFFFFFF // (3 * k) + 1,
                              0xFFFFFFFF // k + 1 if k > 1 else 0)
                 fn(None if lk_in is None else lk_in.ctypes.data, flags.ctypes.data, None, None, st.ctypes.data, S, tc.ctypes.data,
