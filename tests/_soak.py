@@ -68,8 +68,16 @@ def run_seed(seed, max_n=10, threads=8):
         a = ctx.bn_call_batch(seq, lk=lk2, flags=flags)
         b = ctx.bn_call_batch(seq, pl16=pl, flags=flags)
         post2, single2, st2 = ctx.bn_batch(lk2, flags)
+        text, st3 = ctx.bn_call_text_batch(seq, pl16=pl, flags=flags)
         ctx.close()
-        good = all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b)) and np.array_equal(a[3], st2)
+        good = all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b)) and np.array_equal(a[3], st2) and np.array_equal(st3, st2)
+        # the text records of a sample of (site, column) pairs: Python's '%g' of the numbers (what printf / ostream print)
+        computed = np.nonzero((st2 & 3) == 0)[0]
+        for s_ in (rng.choice(computed, size=min(40, len(computed)), replace=False) if len(computed) else []):
+            for j in range(k):
+                rec = text[s_, j]
+                want = "%g,%g,%g:%g,%g,%g:%s\t" % (tuple(a[0][s_, j]) + tuple(a[1][s_, j]) + ({0: "0/0", 1: "0/1"}.get(int(a[2][s_, j]), "1/1"),))
+                good = good and bytes(rec[:rec[-1]]) == want.encode()
         okc = (st2 & 3) == 0
         good = good and np.array_equal(a[2][okc], fs.call_genotypes(post2[okc][:, seq]).reshape(-1, k))
         res.append("call/%s %s" % (name, "ok" if good else "MISMATCH"))

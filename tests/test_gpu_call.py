@@ -105,3 +105,41 @@ def test_packed_pl_input_equals_likelihood_input():
     with pytest.raises(fs.FamseqError):
         ctx.bn_call_batch([0, 0], lk=lk)  # duplicate member
     ctx.close()
+
+
+@pytest.mark.parametrize("label,opt", CALL_ENGINES, ids=[e[0] for e in CALL_ENGINES])
+@pytest.mark.parametrize("cols", [[9, 0, 4], [2], [7, 6, 5, 4, 3, 2, 1, 0], [1, 3, 5, 7, 9, 0, 2]])
+def test_caller_names_other_columns_than_the_sequenced_set(label, opt, cols):
+    """The generated call-path kernels know the pedigree's number of sequenced members at compile time and walk their output rows
+    with that width as a constant; a caller that names another set of columns (fewer samples in this VCF than the model was told are
+    sequenced; odd and even counts, one column) takes the walk that reads the width from the arguments.  Whole chunks and a ragged
+    one, packed PLs and fp64 rows, text records too; against the plain path's posteriors."""
+    ped = fs.synthetic_pedigree("ped10")
+    s = 2 * 1024 + 77 if opt.get("enum_impl") != 0 else 300
+    mo, fa = ped.relations()
+    pl, known, _ = fs.synth.gen_sites(mo, fa, s, seed=fs.synth.SEED_BASE + 7)
+    seq = np.array(cols, np.int32)
+    k = len(seq)
+    lk = np.ones((s, ped.n, 3))
+    lk[:, seq] = fs.synth.pl_to_lk(pl[:, seq])
+    flags = known.astype(np.uint8)
+    ctx = fs.Context(fs.make_model(ped), **opt)
+    post, single, st = ctx.bn_batch(lk, flags)
+    a = ctx.bn_call_batch(seq, lk=lk, flags=flags)
+    b = ctx.bn_call_batch(seq, pl16=np.ascontiguousarray(pl[:, seq]).astype(np.uint16), flags=flags)
+    text, st3 = ctx.bn_call_text_batch(seq, pl16=np.ascontiguousarray(pl[:, seq]).astype(np.uint16), flags=flags)
+    ctx.close()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    gpp, fpp, fgt, st2 = a
+    assert np.array_equal(st, st2) and np.array_equal(st, st3) and not (st & 3).any()
+    np.testing.assert_allclose(gpp, host_phred(single[:, seq]), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(fpp, host_phred(post[:, seq]), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(fgt, fs.call_genotypes(post[:, seq]).reshape(-1, k))
+    for i in (0, 1, 255, 256, 1023, 1024, s - 1):
+        if i >= s:
+            continue
+        for j in range(k):
+            rec = text[i, j]
+            want = "%g,%g,%g:%g,%g,%g:%s\t" % (tuple(gpp[i, j]) + tuple(fpp[i, j]) + ({0: "0/0", 1: "0/1"}.get(int(fgt[i, j]), "1/1"),))
+            assert bytes(rec[:rec[-1]]) == want.encode(), (i, j)
