@@ -142,3 +142,41 @@ def test_device_resident_call_path_gives_the_host_entry_bits(label, opts):
     torch.cuda.synchronize()
     assert np.array_equal(d_text[:2000].cpu().numpy(), t2)
     ctx.close()
+
+
+def test_phase_clock_measuring_aid(tmp_path):
+    """FAMSEQ_PHASE_CLOCK=1 (how the call-path kernel's phases were weighed: DESIGN.md 2.4) generates another source — marks and
+    an extra argument — in its own cache; it must keep compiling, report shares that sum to 100 %, and change no result."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np, famseq_amd as fs
+ped = fs.synthetic_pedigree("ped10")
+mo, fa = ped.relations()
+pl, known, _ = fs.synth.gen_sites(mo, fa, 3000, seed=fs.synth.SEED_BASE + 2)
+ctx = fs.Context(fs.make_model(ped), engine=fs.ENGINE_ELIM)
+out = ctx.bn_call_batch(np.arange(ped.n, dtype=np.int32), pl16=pl.astype(np.uint16), flags=known.astype(np.uint8))
+np.savez(__import__("sys").argv[1], *out)
+'''
+    outs = []
+    for clock in ("0", "1"):
+        env = dict(os.environ, FAMSEQ_KERNEL_CACHE=str(tmp_path / ("kc" + clock)))
+        os.makedirs(env["FAMSEQ_KERNEL_CACHE"])
+        if clock == "1":
+            env["FAMSEQ_PHASE_CLOCK"] = "1"
+        f = str(tmp_path / ("o%s.npz" % clock))
+        p = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, env=env, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert p.returncode == 0, p.stderr[-2000:]
+        if clock == "1":
+            line = [x for x in p.stderr.splitlines() if "famseq phase clock" in x][-1]
+            shares = [float(x.split("]")[1].split("%")[0]) for x in line.split("[")[1:]]
+            assert abs(sum(shares) - 100) < 1.0 and shares[0] > 0 and shares[3] > 0, line
+        else:
+            assert "phase clock" not in p.stderr
+        z = np.load(f)
+        outs.append([z[k] for k in z.files])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
