@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end CLI throughput (timing point T3 of SURVEY.md 8(d)) on seeded synthetic ped10 sites.
-  tools/cli_throughput.py [n_sites]            VCF text through `FamSeq vcf`, `FamSeq pack`, then the packed paths
+  tools/cli_throughput.py [n_sites] [pedigree] VCF text through `FamSeq vcf`, `FamSeq pack`, then the packed paths
   tools/cli_throughput.py [n_sites] --packed   only the packed paths (`FamSeq PL`, `FamSeq PL -binOutput`); the packed
                                                input is written straight from the generator (no VCF text), so
                                                millions of sites take seconds to set up
@@ -14,7 +14,7 @@ from famseq_amd import synth, pedigree, plfile
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if args else 500_000
 packed_only = "--packed" in sys.argv
-ped = pedigree.synthetic_pedigree("ped10")
+ped = pedigree.synthetic_pedigree(args[1] if len(args) > 1 else "ped10")  # tools/cli_throughput.py 5000000 trio
 mo, fa = ped.relations()
 d = tempfile.mkdtemp(prefix="fscli")
 pedf, vcf, fspl = os.path.join(d, "p.ped"), os.path.join(d, "s.vcf"), os.path.join(d, "s.fspl")
