@@ -490,9 +490,12 @@ struct fs_call_args {
 // 3 N independent logarithms per lane — independent for the scheduler only inside one basic block: with fs_phred's own branch
 // per logarithm (the special values) each one was a block of its own, table read -> wait -> nine dependent FMAs, thirty times in
 // a row.  Two members at a time, the six logarithms branch-free and ONE branch behind them for the rare row with a zero or a NaN.
-#define ARGMAX3(a0_, a1_, a2_, slot_) { signed char pk_ = -1; double bs_ = -1; \
-    if (bs_ < a0_) { bs_ = a0_; pk_ = 0; } if (bs_ < a1_) { bs_ = a1_; pk_ = 1; } if (bs_ < a2_) { bs_ = a2_; pk_ = 2; } \
-    s_fgt[tid * NMEM + (slot_)] = pk_; }
+/* (the lowest genotype within 1e-12 relative of the largest posterior: exact ties of the reference — 0.5 / 0.5 at mutation rate 0 —
+   are ties to rounding here; model.cpp famseq_call_genotypes) */
+#define ARGMAX3(a0_, a1_, a2_, slot_) { double bs_ = -1; \
+    if (bs_ < a0_) bs_ = a0_; if (bs_ < a1_) bs_ = a1_; if (bs_ < a2_) bs_ = a2_; \
+    const double th_ = bs_ * (1.0 - 1e-12); \
+    s_fgt[tid * NMEM + (slot_)] = bs_ < 0 ? (signed char)-1 : (a0_ >= th_ ? (signed char)0 : (a1_ >= th_ ? (signed char)1 : (signed char)2)); }
 #define PUT_CALL(V) { _Pragma("unroll") for (int p_ = 0; p_ + 1 < (FS_PHRED_GROUP == 2 ? NMEM : 0); p_ += 2) { \
     const int o0_ = slot_r_[p_], o1_ = slot_r_[p_ + 1]; \
     const double d0_ = V[3 * p_], d1_ = V[3 * p_ + 1], d2_ = V[3 * p_ + 2], d3_ = V[3 * p_ + 3], d4_ = V[3 * p_ + 4], d5_ = V[3 * p_ + 5]; \

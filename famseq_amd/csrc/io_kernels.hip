@@ -100,13 +100,14 @@ __global__ __launch_bounds__(256) void phred_call_kernel(const double *__restric
       fpp[site0 * w3 + e] = st != 0 ? nan : fs_phred(postt[src + g], s_lt);
       if (g == 0) {
         int8_t pick = -1;
-        if (st == 0) {
+        if (st == 0) {  // the lowest genotype within 1e-12 relative of the largest posterior (model.cpp famseq_call_genotypes)
+          const double p0 = postt[src], p1 = postt[src + 1], p2 = postt[src + 2];
           double best = -1;
-          for (int h = 0; h < 3; ++h)
-            if (best < postt[src + h]) {
-              best = postt[src + h];
-              pick = (int8_t)h;
-            }
+          if (best < p0) best = p0;
+          if (best < p1) best = p1;
+          if (best < p2) best = p2;
+          const double thr = best * (1.0 - 1e-12);
+          pick = best < 0 ? (int8_t)-1 : (p0 >= thr ? (int8_t)0 : (p1 >= thr ? (int8_t)1 : (int8_t)2));
         }
         fgt[(site0 + s) * n_seq + k] = pick;
       }

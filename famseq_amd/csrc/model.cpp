@@ -119,16 +119,19 @@ extern "C" int famseq_model_init(famseq_model *m, int32_t n, const int32_t *id, 
   return 0;
 }
 
+// get_postRlt (family.cpp:636-665): the arg-max with strict '<' from -1, i.e. the LOWEST genotype among equals.  Equals are
+// common where they are exact in the reference — a child of a 0/0 x 0/1 couple without data, at mutation rate 0: 0.5 / 0.5 from
+// identical terms in identical order — and only equal to rounding here (another order of the same sum: 1e-15 relative).  So that
+// the call is the reference's there too, a genotype within kCallTie (relative) of the largest posterior counts as equal to it.
+// The device kernels use the same rule (elim_codegen.cpp ARGMAX3, io_kernels.hip).
 extern "C" void famseq_call_genotypes(const double *post, int64_t n_rows, int8_t *geno) {
   for (int64_t r = 0; r < n_rows; ++r) {
+    const double *p = post + 3 * r;
     double best = -1;
-    int8_t pick = -1;
     for (int g = 0; g < 3; ++g)
-      if (best < post[3 * r + g]) {
-        best = post[3 * r + g];
-        pick = (int8_t)g;
-      }
-    geno[r] = pick;
+      if (best < p[g]) best = p[g];
+    const double thr = best * (1.0 - 1e-12);
+    geno[r] = best < 0 ? (int8_t)-1 : (p[0] >= thr ? (int8_t)0 : (p[1] >= thr ? (int8_t)1 : (int8_t)2));  // (a NaN row leaves best at -1)
   }
 }
 

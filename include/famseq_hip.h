@@ -266,8 +266,10 @@ int famseq_stream_probe(famseq_ctx *ctx, int64_t n_doubles, const double *d_in, 
 void *famseq_alloc_pinned(size_t bytes);
 void famseq_free_pinned(void *p);
 
-/* get_postRlt (family.cpp:636-665) for one N x 3 posterior row block: arg-max with
- * strict '<' starting from -1, so ties resolve to the lowest genotype. */
+/* get_postRlt (family.cpp:636-665) for one N x 3 posterior row block: arg-max with strict '<' starting from -1, so ties
+ * resolve to the lowest genotype — here with posteriors within 1e-12 (relative) of the largest counting as ties: the
+ * reference's exact ties (a 0.5 / 0.5 child at mutation rate 0) are ties to rounding only in another order of summation,
+ * and the call should be the reference's there too.  The device kernels (fgt above, the text records) use the same rule. */
 void famseq_call_genotypes(const double *post, int64_t n_rows, int8_t *geno);
 
 #ifdef __cplusplus

@@ -331,3 +331,22 @@ def test_device_text_is_the_host_formatter_text(vcf, ped, extra, batch, tmp_path
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and outs[0].count(b":GPP:FPP:FGT") >= 10
+
+
+@pytest.mark.parametrize("first", [0, 8, 16])
+def test_differential_fuzz_against_the_compiled_reference_cli(first):
+    """tools/cli_fuzz.py, eight seeds per case: random pedigrees (loops, unsequenced members, a sample that is not in the PED),
+    random VCF lines of every kind the reference's driver tells apart, random -v / -a / -LRC / -mRate — `bin/FamSeq vcf` against
+    the reference's own command line compiled from its sources (oracle/_ref/FamSeq_ref), line by line."""
+    import sys
+    import tempfile
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cli_fuzz
+
+    if not os.path.exists(cli_fuzz.REF):
+        pytest.skip("oracle/_ref/FamSeq_ref is not built here")
+    with tempfile.TemporaryDirectory(prefix="fsfuzz") as tmp:
+        for seed in range(first, first + 8):
+            line, failed = cli_fuzz.run_seed(seed, tmp)
+            assert not failed, line

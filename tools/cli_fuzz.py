@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""tools/cli_fuzz.py [first_seed] [n_seeds] — differential fuzz of `bin/FamSeq vcf` against the reference's own command line
+compiled from its sources (oracle/_ref/FamSeq_ref: oracle/Makefile; test infrastructure, like everything under oracle/).
+
+Per seed: a randomly grown pedigree of 3-8 members (marriage loops on even seeds, some members unsequenced), a VCF whose sample
+columns are the sequenced members in a shuffled order plus one sample that is not in the PED, ~150 data lines drawn from the
+kinds the reference's driver tells apart (file.cpp:362-555) — plain PL sites, known / unknown IDs, chrX / chrY / MT / unplaced
+contigs, "chr" prefixes, indels and multi-base alleles, ALT ".", FORMAT orders with PL first / last / missing, GL instead of PL,
+missing samples, all samples missing, sample fields shorter than FORMAT, huge PLs (exactly 0 likelihood), flat PLs, sites that
+fail (all likelihoods 0 for a member), shortcut candidates (both non-zero PLs >= 160) — and a random choice of -v / -a / -LRC /
+-mRate.  Both programs run on the same files; the outputs are compared line by line with tests/test_cli_gpu.py's rule (text
+identical, numbers to 1e-5 relative).  Runs on the GPU box; prints one line per seed, exits non-zero on the first difference."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from famseq_amd import pedigree  # noqa: E402
+from famseq_amd.prebuild_sets import soak_pedigree  # noqa: E402
+
+CLI = os.path.join(ROOT, "bin", "FamSeq")
+REF = os.path.join(ROOT, "oracle", "_ref", "FamSeq_ref")
+
+
+def pl_triple(rng, kind):
+    t = int(rng.randint(0, 3))
+    if kind == "flat":
+        return [0, 0, 0]
+    if kind == "huge":
+        v = [int(rng.choice([3300, 9999, 65000])), int(rng.choice([3300, 9999])), int(rng.choice([3300, 5000]))]
+        v[t] = 0
+        return v
+    if kind == "confident":  # shortcut candidate: both other PLs >= 160
+        v = [int(rng.randint(160, 2000)) for _ in range(3)]
+        v[t] = 0
+        return v
+    v = [int(rng.randint(1, 260)) for _ in range(3)]
+    v[t] = 0
+    return v
+
+
+def make_line(rng, k, pos):
+    kind = rng.choice(["plain"] * 10 + ["x", "chrx", "y", "mt", "unplaced", "chrN", "indel", "multi", "altdot", "nopl", "gl", "ad_pl",
+                                        "pl_first", "some_missing", "all_missing", "short_field", "huge", "flat", "confident", "fail"])
+    chrom = str(rng.randint(1, 23))
+    ref, alt, fmt = "A", "G", "GT:PL"
+    if kind in ("x",):
+        chrom = "X"
+    elif kind == "chrx":
+        chrom = rng.choice(["chrX", "CHRX"])
+    elif kind == "y":
+        chrom = rng.choice(["Y", "chrY"])
+    elif kind == "mt":
+        chrom = "MT"
+    elif kind == "unplaced":
+        chrom = "GL000207.1"
+    elif kind == "chrN":
+        chrom = "chr%d" % rng.randint(1, 23)
+    elif kind == "indel":
+        ref, alt = [("AT", "G"), ("A", "GT"), ("-", "G"), ("A", "-")][int(rng.randint(0, 4))]
+    elif kind == "multi":
+        alt = "G,T"
+    elif kind == "altdot":
+        alt = "."
+    rsid = ("rs%d" % pos) if rng.rand() < 0.3 else "."
+    if kind == "nopl":
+        fmt = "GT:DP"
+    elif kind == "gl":
+        fmt = "GT:GL"
+    elif kind == "ad_pl":
+        fmt = "GT:AD:DP:PL"
+    elif kind == "pl_first":
+        fmt = "PL:GT"
+    samples = []
+    for j in range(k):
+        sub = "plain"
+        if kind in ("huge", "flat", "confident"):
+            sub = kind if rng.rand() < 0.7 else "plain"
+        p = pl_triple(rng, sub)
+        if kind == "fail" and j == 0:
+            p = [9999, 9999, 9999]  # every likelihood of this sample exactly 0: calPostProbSingle fails (status 1)
+        gt = rng.choice(["0/0", "0/1", "1/1"])
+        if kind == "all_missing" or (kind == "some_missing" and rng.rand() < 0.4):
+            samples.append("./.")
+            continue
+        if kind == "nopl":
+            samples.append("%s:%d" % (gt, rng.randint(1, 60)))
+        elif kind == "gl":
+            samples.append("%s:%s" % (gt, ",".join("%.2f" % (-x / 10.0) if x else "0" for x in p)))
+        elif kind == "ad_pl":
+            samples.append("%s:%d,%d:%d:%d,%d,%d" % (gt, rng.randint(0, 30), rng.randint(0, 30), rng.randint(1, 60), p[0], p[1], p[2]))
+        elif kind == "pl_first":
+            samples.append("%d,%d,%d:%s" % (p[0], p[1], p[2], gt))
+        elif kind == "short_field" and rng.rand() < 0.3:
+            samples.append(gt + ":.")  # five characters or more, but fewer sub-fields than FORMAT has
+            fmt = "GT:AD:PL"
+        elif kind == "short_field":
+            samples.append("%s:3,4:%d,%d,%d" % (gt, p[0], p[1], p[2]))
+            fmt = "GT:AD:PL"
+        else:
+            samples.append("%s:%d,%d,%d" % (gt, p[0], p[1], p[2]))
+    return "\t".join([chrom, str(pos), rsid, ref, alt, "50", "PASS", "DP=9", fmt] + samples)
+
+
+def same_output(got_path, ref_path):
+    """tests/test_cli_gpu.py's rule — text identical, GPP / FPP numbers to 1e-5 relative — with one allowance: the called genotype
+    (FGT) may differ where the posteriors of the two genotypes called are a tie as printed.  The reference's own rounding decides
+    such ties (two samples of one line with the same printed FPP "3.46787,10,3.46787" are called 1/1 and 0/0 by the reference:
+    seed 4), which no other order of summation can reproduce; this library calls the lowest genotype within 1e-12 of the maximum.
+    -> (result lines, calls that differ at ties)."""
+    from test_cli_gpu import num_close
+
+    got, ref = open(got_path).read().split("\n"), open(ref_path).read().split("\n")
+    assert len(got) == len(ref), "line count %d vs %d" % (len(got), len(ref))
+    n_results = n_ties = 0
+    for ln, (g, r) in enumerate(zip(got, ref), 1):
+        n_results += ":GPP:FPP:FGT" in r and not r.startswith("#")
+        if g == r:
+            continue
+        gt, rt = g.split("\t"), r.split("\t")
+        assert len(gt) == len(rt), "line %d: column count" % ln
+        for a, b in zip(gt, rt):
+            if a == b:
+                continue
+            ga, rb = a.split(":"), b.split(":")
+            assert len(ga) == len(rb) >= 3 and ga[:-3] == rb[:-3], "line %d: %r vs %r" % (ln, a, b)
+            for u, v in zip(ga[-3:-1], rb[-3:-1]):  # GPP, FPP
+                us, vs = u.split(","), v.split(",")
+                assert len(us) == len(vs) and all(num_close(p, q) for p, q in zip(us, vs)), "line %d: %r vs %r" % (ln, a, b)
+            if ga[-1] != rb[-1]:
+                idx = {"0/0": 0, "0/1": 1, "1/1": 2}
+                fpp = rb[-2].split(",")
+                assert num_close(fpp[idx[ga[-1]]], fpp[idx[rb[-1]]]), "line %d: call %s vs %s without a tie: %r" % (ln, ga[-1], rb[-1], b)
+                n_ties += 1
+    return n_results, n_ties
+
+
+def run_seed(seed, tmp):
+    rng, ped, mu = soak_pedigree(seed, 8)
+    seq = [i for i in range(ped.n) if ped.sequenced[i]]
+    rng.shuffle(seq)
+    names = [ped.names[i] for i in seq]
+    extra_at = int(rng.randint(0, len(names) + 1))
+    names.insert(extra_at, "not_in_ped")
+    pedf, vcf = os.path.join(tmp, "p.ped"), os.path.join(tmp, "s.vcf")
+    pedigree.write_ped(ped, pedf)
+    with open(vcf, "w") as f:
+        f.write("##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+                "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"PL\">\n##INFO=<ID=DP,Number=1,Type=Integer,Description=\"d\">\n"
+                "##contig=<ID=1,length=249250621>\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+        for i in range(int(rng.randint(60, 220))):
+            f.write(make_line(rng, len(names), 100 + 7 * i) + "\n")
+    flags = [[], ["-v"], ["-a"]][int(rng.randint(0, 3))]
+    if mu != 1e-7:
+        flags = flags + ["-mRate", "%g" % mu]
+    if rng.rand() < 0.4:
+        flags = flags + ["-LRC", "%.3f" % rng.uniform(0.5, 0.9999)]
+    outs = []
+    for exe, tag in ((REF, "ref"), (CLI, "hip")):
+        out = os.path.join(tmp, "o_%s.vcf" % tag)
+        p = subprocess.run([exe, "vcf", "-vcfFile", vcf, "-pedFile", pedf, "-output", out, "-method", "1"] + flags,
+                           capture_output=True, text=True, timeout=600)
+        if p.returncode != 0 or not os.path.exists(out):
+            return "seed %d n=%d: %s exited %d: %s" % (seed, ped.n, tag, p.returncode, (p.stdout + p.stderr)[-300:]), tag != "ref"
+        outs.append((out, p.stdout))
+    try:
+        n_res, n_ties = same_output(outs[1][0], outs[0][0])
+    except AssertionError as e:
+        keep = os.path.join(ROOT, "gpurun_out", "cli_fuzz_seed_%d" % seed)
+        os.makedirs(keep, exist_ok=True)
+        for f in (pedf, vcf, outs[0][0], outs[1][0]):
+            subprocess.call(["cp", f, keep])
+        return "seed %d n=%d %s: DIFFERENT: %s (files kept in %s)" % (seed, ped.n, " ".join(flags), str(e)[:300], keep), True
+    warn_ref, warn_hip = outs[0][1].count("hasn't been calculated"), outs[1][1].count("hasn't been calculated")
+    if warn_ref != warn_hip:
+        return "seed %d: %d warnings from the reference, %d from bin/FamSeq" % (seed, warn_ref, warn_hip), True
+    return "seed %3d n=%d k=%d %-28s %3d result lines, %d failed-site warnings: same%s" % (
+        seed, ped.n, len(seq), " ".join(flags), n_res, warn_ref, " (%d calls differ at ties)" % n_ties if n_ties else ""), False
+
+
+def main():
+    first, count = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 0), (2, 40)))
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/FamSeq_ref is not built (make -C oracle ref, where /root/reference exists)")
+    bad = 0
+    with tempfile.TemporaryDirectory(prefix="fsfuzz") as tmp:
+        for seed in range(first, first + count):
+            line, failed = run_seed(seed, tmp)
+            print(line, flush=True)
+            bad += failed
+            if failed:
+                break
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
