@@ -8,7 +8,7 @@ kinds the reference's driver tells apart (file.cpp:362-555) — plain PL sites, 
 contigs, "chr" prefixes, indels and multi-base alleles, ALT ".", FORMAT orders with PL first / last / missing, GL instead of PL,
 missing samples, all samples missing, sample fields shorter than FORMAT, huge PLs (exactly 0 likelihood), flat PLs, sites that
 fail (all likelihoods 0 for a member), shortcut candidates (both non-zero PLs >= 160) — and a random choice of -v / -a / -LRC /
--mRate.  Both programs run on the same files; the outputs are compared line by line with tests/test_cli_gpu.py's rule (text
+-mRate, and -method 2 (the reference's peeling against the sum-product engine) on half of the loop-free pedigrees.  Both programs run on the same files; the outputs are compared line by line with tests/test_cli_gpu.py's rule (text
 identical, numbers to 1e-5 relative).  Runs on the GPU box; prints one line per seed, exits non-zero on the first difference."""
 import os
 import subprocess
@@ -107,6 +107,20 @@ def make_line(rng, k, pos):
     return "\t".join([chrom, str(pos), rsid, ref, alt, "50", "PASS", "DP=9", fmt] + samples)
 
 
+def underflowing(a, b):
+    """Both Phred values beyond 3000, i.e. probabilities below 1e-300: at and below the smallest normal double (1e-308 = Phred 3076)
+    a product keeps fewer and fewer bits, and which of them depends on the order of the factors (seed 341: 3130.96 against the
+    reference's 3130.23 for a posterior of 1e-313).  There the two need only agree to 1 %, and an exact zero (99999) on one side may
+    be anything below 1e-250 on the other."""
+    try:
+        x, y = float(a), float(b)
+    except ValueError:
+        return False
+    if max(x, y) == 99999:  # a zero on one side: an intermediate product underflowed there (the reference's peeling multiplies messages
+        return min(x, y) > 2500  # of 1e-100 and less before it normalises: seed 395, 2804.01 here against its 99999)
+    return min(x, y) > 3000 and abs(x - y) <= 0.01 * max(x, y)
+
+
 def same_output(got_path, ref_path):
     """tests/test_cli_gpu.py's rule — text identical, GPP / FPP numbers to 1e-5 relative — with one allowance: the called genotype
     (FGT) may differ where the posteriors of the two genotypes called are a tie as printed.  The reference's own rounding decides
@@ -131,7 +145,7 @@ def same_output(got_path, ref_path):
             assert len(ga) == len(rb) >= 3 and ga[:-3] == rb[:-3], "line %d: %r vs %r" % (ln, a, b)
             for u, v in zip(ga[-3:-1], rb[-3:-1]):  # GPP, FPP
                 us, vs = u.split(","), v.split(",")
-                assert len(us) == len(vs) and all(num_close(p, q) for p, q in zip(us, vs)), "line %d: %r vs %r" % (ln, a, b)
+                assert len(us) == len(vs) and all(num_close(p, q) or underflowing(p, q) for p, q in zip(us, vs)), "line %d: %r vs %r" % (ln, a, b)
             if ga[-1] != rb[-1]:
                 idx = {"0/0": 0, "0/1": 1, "1/1": 2}
                 fpp = rb[-2].split(",")
@@ -161,10 +175,13 @@ def run_seed(seed, tmp):
         flags = flags + ["-mRate", "%g" % mu]
     if rng.rand() < 0.4:
         flags = flags + ["-LRC", "%.3f" % rng.uniform(0.5, 0.9999)]
+    # loop-free pedigrees (odd seeds) also go through -method 2: the reference's peeling against the sum-product engine
+    method = "2" if seed % 2 == 1 and rng.rand() < 0.5 else "1"
+    flags = ["-method", method] + flags
     outs = []
     for exe, tag in ((REF, "ref"), (CLI, "hip")):
         out = os.path.join(tmp, "o_%s.vcf" % tag)
-        p = subprocess.run([exe, "vcf", "-vcfFile", vcf, "-pedFile", pedf, "-output", out, "-method", "1"] + flags,
+        p = subprocess.run([exe, "vcf", "-vcfFile", vcf, "-pedFile", pedf, "-output", out] + flags,
                            capture_output=True, text=True, timeout=600)
         if p.returncode != 0 or not os.path.exists(out):
             return "seed %d n=%d: %s exited %d: %s" % (seed, ped.n, tag, p.returncode, (p.stdout + p.stderr)[-300:]), tag != "ref"
