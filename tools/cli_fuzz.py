@@ -9,7 +9,7 @@ contigs, "chr" prefixes, indels and multi-base alleles, ALT ".", FORMAT orders w
 missing samples, all samples missing, sample fields shorter than FORMAT, huge PLs (exactly 0 likelihood), flat PLs, sites that
 fail (all likelihoods 0 for a member), shortcut candidates (both non-zero PLs >= 160) — and a random choice of -v / -a / -LRC /
 -mRate, and -method 2 (the reference's peeling against the sum-product engine) on half of the loop-free pedigrees.  Both programs run on the same files; the outputs are compared line by line with tests/test_cli_gpu.py's rule (text
-identical, numbers to 1e-5 relative).  Runs on the GPU box; prints one line per seed, exits non-zero on the first difference."""
+identical, numbers to 1e-5 relative).  Each seed also runs the LK driver on a random likelihood table (run_seed_lk).  Runs on the GPU box; prints one line per seed, exits non-zero on the first difference."""
 import os
 import subprocess
 import sys
@@ -201,6 +201,50 @@ def run_seed(seed, tmp):
         seed, ped.n, len(seq), " ".join(flags), n_res, warn_ref, " (%d calls differ at ties)" % n_ties if n_ties else ""), False
 
 
+def run_seed_lk(seed, tmp):
+    """The LK driver (file.cpp:1640-1886) on the same pedigree: a likelihood table of 40-120 rows in one of the four -lkType scales,
+    columns shuffled, one column that is not in the PED, now and then a short row (dropped) or a row with a zero column."""
+    rng, ped, mu = soak_pedigree(seed, 8)
+    rng = np.random.RandomState(77000 + seed)
+    seq = [i for i in range(ped.n) if ped.sequenced[i]]
+    rng.shuffle(seq)
+    names = [ped.names[i] for i in seq]
+    names.insert(int(rng.randint(0, len(names) + 1)), "not_in_ped")
+    typ = ["n", "log10", "ln", "PS"][int(rng.randint(0, 4))]
+    pedf, lkf = os.path.join(tmp, "p.ped"), os.path.join(tmp, "s.lk")
+    pedigree.write_ped(ped, pedf)
+    with open(lkf, "w") as f:
+        f.write("\t".join(names) + "\t\n")
+        for _ in range(int(rng.randint(40, 121))):
+            cells = []
+            for _c in names:
+                lk = 10.0 ** (-rng.uniform(0, 12, 3))
+                lk[int(rng.randint(0, 3))] = rng.uniform(0.05, 1.0)
+                if rng.rand() < 0.02:
+                    lk[:] = 0.0 if typ == "n" else lk  # a member without any likelihood: the site fails
+                v = {"n": lk, "log10": np.log10(np.maximum(lk, 1e-300)), "ln": np.log(np.maximum(lk, 1e-300)),
+                     "PS": -10 * np.log10(np.maximum(lk, 1e-300))}[typ]
+                cells.append(",".join("%.4g" % x for x in v))
+            f.write("\t".join(cells) + "\t\n")
+    flags = ["-lkType", typ] + ([] if mu == 1e-7 else ["-mRate", "%g" % mu])
+    outs = []
+    for exe, tag in ((REF, "ref"), (CLI, "hip")):
+        out = os.path.join(tmp, "l_%s.txt" % tag)
+        p = subprocess.run([exe, "LK", "-lkFile", lkf, "-pedFile", pedf, "-output", out] + flags, capture_output=True, text=True, timeout=600)
+        if p.returncode != 0 or not os.path.exists(out):
+            return "seed %d LK: %s exited %d: %s" % (seed, tag, p.returncode, (p.stdout + p.stderr)[-300:]), tag != "ref"
+        outs.append(out)
+    try:
+        n_res, n_ties = same_output(outs[1], outs[0])
+    except AssertionError as e:
+        keep = os.path.join(ROOT, "gpurun_out", "cli_fuzz_lk_seed_%d" % seed)
+        os.makedirs(keep, exist_ok=True)
+        for f in (pedf, lkf, outs[0], outs[1]):
+            subprocess.call(["cp", f, keep])
+        return "seed %d LK %s: DIFFERENT: %s (files kept in %s)" % (seed, " ".join(flags), str(e)[:300], keep), True
+    return "seed %3d LK  %-24s %3d result lines: same%s" % (seed, " ".join(flags), n_res, " (%d calls differ at ties)" % n_ties if n_ties else ""), False
+
+
 def main():
     first, count = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 0), (2, 40)))
     if not os.path.exists(REF):
@@ -208,10 +252,11 @@ def main():
     bad = 0
     with tempfile.TemporaryDirectory(prefix="fsfuzz") as tmp:
         for seed in range(first, first + count):
-            line, failed = run_seed(seed, tmp)
-            print(line, flush=True)
-            bad += failed
-            if failed:
+            for one in (run_seed, run_seed_lk):
+                line, failed = one(seed, tmp)
+                print(line, flush=True)
+                bad += failed
+            if bad:
                 break
     sys.exit(1 if bad else 0)
 
