@@ -1235,12 +1235,19 @@ extern "C" int famseq_bn_call_batch_device(famseq_ctx *c, int64_t n_sites, const
   const int N = c->model.n_members;
   const bool want_text = d_text != nullptr;
   // what the stages write: the caller's arrays, or scratch of this context's for those the caller does not ask for but a later
-  // stage reads (the text kernel reads all three) or a separate-stages batch passes through (fp64 rows in and out)
-  const size_t row = size_t(3) * N * sizeof(double), crow = size_t(3) * n_seq * sizeof(double);
-  if (c->dev_tmp_sites < n_sites || c->dev_tmp_seq < n_seq) {
+  // stage reads (the text kernel reads all three) or a separate-stages batch passes through (fp64 rows in and out).  Scratch is
+  // allocated for what this call needs only: a fused batch with every output given needs none.
+  const size_t row = size_t(3) * N * sizeof(double);
+  const bool elim = c->engine == FAMSEQ_ENGINE_ELIM;
+  bool will_fuse = !c->big && (elim || ((c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites)) && pick_group_digits(c, n_sites) == 0));
+  if (will_fuse) will_fuse = load_call_kernel(c, elim) && !(!elim && d_pl16 && c->lane_reads_rows != 0);
+  const bool need_rows = !will_fuse, need_called = !will_fuse || (want_text && !(d_gpp && d_fpp && d_fgt)), need_status = !d_status;
+  if ((need_rows && (!c->dev_tmp[0] || c->dev_tmp_sites < n_sites)) || (need_called && (!c->dev_tmp[3] || c->dev_tmp_sites < n_sites || c->dev_tmp_seq < n_seq)) ||
+      (need_status && (!c->dev_tmp_status || c->dev_tmp_sites < n_sites))) {
     HIP_TRY(c, hipStreamSynchronize(stream));  // nothing of an earlier call may still use what is freed here
     const int64_t cap = std::max(n_sites, c->dev_tmp_sites);
     const int seqcap = std::max<int>(n_seq, c->dev_tmp_seq);
+    const bool had_rows = c->dev_tmp[0] != nullptr, had_called = c->dev_tmp[3] != nullptr;
     for (double *&q : c->dev_tmp) {
       if (q) (void)hipFree(q);
       q = nullptr;
@@ -1248,13 +1255,15 @@ extern "C" int famseq_bn_call_batch_device(famseq_ctx *c, int64_t n_sites, const
     if (c->dev_tmp_fgt) (void)hipFree(c->dev_tmp_fgt);
     if (c->dev_tmp_status) (void)hipFree(c->dev_tmp_status);
     c->dev_tmp_fgt = nullptr, c->dev_tmp_status = nullptr, c->dev_tmp_sites = 0;
-    for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp[i]), size_t(cap) * row));
-    for (int i = 3; i < 5; ++i) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp[i]), size_t(cap) * 3 * seqcap * sizeof(double)));
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp_fgt), size_t(cap) * seqcap));
+    if (need_rows || had_rows)
+      for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp[i]), size_t(cap) * row));
+    if (need_called || had_called) {
+      for (int i = 3; i < 5; ++i) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp[i]), size_t(cap) * 3 * seqcap * sizeof(double)));
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp_fgt), size_t(cap) * seqcap));
+    }
     HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->dev_tmp_status), size_t(cap)));
     c->dev_tmp_sites = cap, c->dev_tmp_seq = seqcap;
   }
-  (void)crow;
   double *gpp = d_gpp ? d_gpp : (want_text ? c->dev_tmp[3] : nullptr), *fpp = d_fpp ? d_fpp : (want_text ? c->dev_tmp[4] : nullptr);
   int8_t *fgt = d_fgt ? d_fgt : (want_text ? c->dev_tmp_fgt : nullptr);
   uint8_t *status = d_status ? d_status : c->dev_tmp_status;
@@ -1285,6 +1294,7 @@ extern "C" int famseq_bn_call_batch_device(famseq_ctx *c, int64_t n_sites, const
   const bool fused = launch_engine_fused(c, n_sites, d_lk, d_flags, status, d_pl16 != nullptr, c->d_call_dev, stream, &e);
   if (fused) HIP_TRY(c, e);
   if (!fused) {
+    if (!c->dev_tmp[0] || !c->dev_tmp[3]) return fail(c, FAMSEQ_E_HIP, "call path: the batch left the fused kernel without scratch rows (internal)");
     const double *lk = d_lk;
     if (d_pl16) {
       HIP_TRY(c, launch_unpack_pl16(d_pl16, c->d_col, c->d_lut, N, n_seq, n_sites, c->dev_tmp[0], stream));

@@ -348,5 +348,6 @@ def test_differential_fuzz_against_the_compiled_reference_cli(first):
         pytest.skip("oracle/_ref/FamSeq_ref is not built here")
     with tempfile.TemporaryDirectory(prefix="fsfuzz") as tmp:
         for seed in range(first, first + 8):
-            line, failed = cli_fuzz.run_seed(seed, tmp)
-            assert not failed, line
+            for one in (cli_fuzz.run_seed, cli_fuzz.run_seed_lk):  # the vcf driver, then the LK driver on a random table
+                line, failed = one(seed, tmp)
+                assert not failed, line
