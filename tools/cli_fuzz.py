@@ -8,7 +8,7 @@ kinds the reference's driver tells apart (file.cpp:362-555) — plain PL sites, 
 contigs, "chr" prefixes, indels and multi-base alleles, ALT ".", FORMAT orders with PL first / last / missing, GL instead of PL,
 missing samples, all samples missing, sample fields shorter than FORMAT, huge PLs (exactly 0 likelihood), flat PLs, sites that
 fail (all likelihoods 0 for a member), shortcut candidates (both non-zero PLs >= 160) — and a random choice of -v / -a / -LRC /
--mRate, and -method 2 (the reference's peeling against the sum-product engine) on half of the loop-free pedigrees.  Both programs run on the same files; the outputs are compared line by line with tests/test_cli_gpu.py's rule (text
+-mRate / custom priors / a location file, and -method 2 (the reference's peeling against the sum-product engine) on half of the loop-free pedigrees.  Both programs run on the same files; the outputs are compared line by line with tests/test_cli_gpu.py's rule (text
 identical, numbers to 1e-5 relative).  Each seed also runs the LK driver on a random likelihood table (run_seed_lk).  Runs on the GPU box; prints one line per seed, exits non-zero on the first difference."""
 import os
 import subprocess
@@ -175,6 +175,20 @@ def run_seed(seed, tmp):
         flags = flags + ["-mRate", "%g" % mu]
     if rng.rand() < 0.4:
         flags = flags + ["-LRC", "%.3f" % rng.uniform(0.5, 0.9999)]
+    if rng.rand() < 0.25:  # custom priors (family.cpp:91-109): autosome rare / common, chrX male rare / common
+        def probs(k):
+            v = rng.dirichlet(np.ones(k) * 2)
+            return ["%.4f" % x for x in v]
+        flags = flags + ["-genoProbN"] + probs(3) + ["-genoProbK"] + probs(3) + ["-genoProbXN"] + probs(2) + ["-genoProbXK"] + probs(2)
+    if rng.rand() < 0.25:  # a location file (file.cpp:235-298): a random third of the positions, chromosome names as the file has them
+        locf = os.path.join(tmp, "s.loc")
+        with open(locf, "w") as f:
+            for ln in open(vcf):
+                if not ln.startswith("#") and rng.rand() < 0.35:
+                    t = ln.split("\t", 2)
+                    c = t[0][3:] if t[0].lower().startswith("chr") else t[0]
+                    f.write("%s\t%s\n" % (c, t[1]))
+        flags = flags + ["-l", locf]
     # loop-free pedigrees (odd seeds) also go through -method 2: the reference's peeling against the sum-product engine
     method = "2" if seed % 2 == 1 and rng.rand() < 0.5 else "1"
     flags = ["-method", method] + flags
@@ -194,6 +208,7 @@ def run_seed(seed, tmp):
         for f in (pedf, vcf, outs[0][0], outs[1][0]):
             subprocess.call(["cp", f, keep])
         return "seed %d n=%d %s: DIFFERENT: %s (files kept in %s)" % (seed, ped.n, " ".join(flags), str(e)[:300], keep), True
+    flags = [os.path.basename(x) if x.startswith(tmp) else x for x in flags]
     warn_ref, warn_hip = outs[0][1].count("hasn't been calculated"), outs[1][1].count("hasn't been calculated")
     if warn_ref != warn_hip:
         return "seed %d: %d warnings from the reference, %d from bin/FamSeq" % (seed, warn_ref, warn_hip), True
