@@ -444,8 +444,8 @@ bool load_call_kernel(famseq_ctx *c, bool elim) {
 // (famseq_bn_call_batch).  Served by the call-path forms of the generated kernels (one lane per site);
 // returns false when this batch goes through the separate stages instead (team kernel, lanes-per-site
 // mode, or a lane kernel that re-reads fp64 rows from global memory while the input is packed).
-bool launch_engine_fused(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, uint8_t *d_status,
-                         bool packed_in, const CallIO *d_io, hipStream_t stream, hipError_t *err) {
+// Does this batch go through a generated kernel's call-path form (loading it on first use)?  The one place that decides.
+bool call_fuses(famseq_ctx *c, int64_t n_sites, bool packed_in) {
   const bool elim = c->engine == FAMSEQ_ENGINE_ELIM;
   if (c->big) return false;  // no call-path form of the wide-pedigree kernel: separate stages
   if (!elim) {
@@ -454,6 +454,13 @@ bool launch_engine_fused(famseq_ctx *c, int64_t n_sites, const double *d_lk, con
   }
   if (!load_call_kernel(c, elim)) return false;
   if (!elim && packed_in && c->lane_reads_rows != 0) return false;  // (set by load_call_kernel for the variant it took)
+  return true;
+}
+
+bool launch_engine_fused(famseq_ctx *c, int64_t n_sites, const double *d_lk, const uint8_t *d_flags, uint8_t *d_status,
+                         bool packed_in, const CallIO *d_io, hipStream_t stream, hipError_t *err) {
+  const bool elim = c->engine == FAMSEQ_ENGINE_ELIM;
+  if (!call_fuses(c, n_sites, packed_in)) return false;
   if (!elim) c->last_group_digits = 0;
   *err = launch_generated(c, elim ? c->elim_call.fn : c->lane_call.fn, elim ? elim_block_threads(c->model, true) : enumgen_block_threads(c->model),
                           elim ? c->elim_call_blocks_per_cu : c->lane_call_blocks_per_cu, n_sites, d_lk, d_flags, nullptr, nullptr,
@@ -1238,9 +1245,7 @@ extern "C" int famseq_bn_call_batch_device(famseq_ctx *c, int64_t n_sites, const
   // stage reads (the text kernel reads all three) or a separate-stages batch passes through (fp64 rows in and out).  Scratch is
   // allocated for what this call needs only: a fused batch with every output given needs none.
   const size_t row = size_t(3) * N * sizeof(double);
-  const bool elim = c->engine == FAMSEQ_ENGINE_ELIM;
-  bool will_fuse = !c->big && (elim || ((c->enum_impl == 1 || (c->enum_impl < 0 && n_sites >= c->lane_min_sites)) && pick_group_digits(c, n_sites) == 0));
-  if (will_fuse) will_fuse = load_call_kernel(c, elim) && !(!elim && d_pl16 && c->lane_reads_rows != 0);
+  const bool will_fuse = call_fuses(c, n_sites, d_pl16 != nullptr);
   const bool need_rows = !will_fuse, need_called = !will_fuse || (want_text && !(d_gpp && d_fpp && d_fgt)), need_status = !d_status;
   if ((need_rows && (!c->dev_tmp[0] || c->dev_tmp_sites < n_sites)) || (need_called && (!c->dev_tmp[3] || c->dev_tmp_sites < n_sites || c->dev_tmp_seq < n_seq)) ||
       (need_status && (!c->dev_tmp_status || c->dev_tmp_sites < n_sites))) {
