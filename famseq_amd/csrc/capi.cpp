@@ -741,6 +741,26 @@ int tune(famseq_ctx *c) {
 
 }  // namespace
 
+namespace {
+// FAMSEQ_PHASE_CLOCK on the plain kernels: their counters sit in a module global; print and clear them.
+void report_phase_clock(famseq_ctx *c) {
+  for (JitKernel *k : {&c->elim, &c->lane}) {
+    if (!k->module) continue;
+    hipDeviceptr_t p = nullptr;
+    size_t bytes = 0;
+    if (hipModuleGetGlobal(&p, &bytes, k->module, "fs_phase_clk") != hipSuccess || bytes < 8 * sizeof(unsigned long long)) continue;
+    unsigned long long ph[8] = {};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(ph, p, sizeof ph, hipMemcpyDeviceToHost) != hipSuccess) continue;
+    unsigned long long tot = 0;
+    for (unsigned long long v : ph) tot += v;
+    std::fprintf(stderr, "famseq phase clock, %s kernel (wave cycles):", k == &c->elim ? "sum-product" : "enumeration");
+    for (int i = 0; i < 8; ++i) std::fprintf(stderr, " [%d] %.1f%%", i, tot ? 100.0 * double(ph[i]) / double(tot) : 0.0);
+    std::fprintf(stderr, "  total %llu\n", tot);
+    (void)hipMemset(p, 0, sizeof ph);
+  }
+}
+}  // namespace
+
 extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) {
   if (!c || !key) return FAMSEQ_E_ARG;
   const std::string k(key);
@@ -821,6 +841,12 @@ extern "C" int famseq_set_option(famseq_ctx *c, const char *key, int64_t value) 
       if (rc != 0) return rc;
     }
     c->engine = (int)value;
+    return 0;
+  }
+  else if (k == "phase_clock_report") {  // measuring aid: see report_phase_clock
+    if (c->device < 0) return fail(c, FAMSEQ_E_NODEVICE, "phase_clock_report needs a device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    report_phase_clock(c);
     return 0;
   }
   else if (k == "chunk_sites") {

@@ -744,13 +744,17 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
   // FAMSEQ_PHASE_CLOCK (measuring aid, call path only): the waves add the cycles of each phase of the chunk loop to counters
   // behind call_g->phase_clk — 0 stage in, 1 single posterior + Phred, 2 GPP out, 3 message passing, 4 Phred of the marginals,
   // 5 FPP / FGT / status out (famseq_bn_call_batch prints the shares).  Without the variable the source is unchanged.
-  const bool phase_clock = call_mode && std::getenv("FAMSEQ_PHASE_CLOCK") != nullptr;
+  const bool phase_clock = std::getenv("FAMSEQ_PHASE_CLOCK") != nullptr;  // (plain kernels: counters in a module global, fs_phase_clk)
   // How much of the output work the scheduler sees at once (kCallHelpers): logarithms of two members or of one per basic block,
   // the stage-out walk with the row width as a constant or as read from the arguments.  More at once = more registers.
   int phred_group = 2;
   const bool ct_out = call_ct_out;
   if (const char *e = std::getenv("FAMSEQ_CALL_PHRED_GROUP")) phred_group = std::atoi(e) == 1 ? 1 : 2;  // tuning aid
   auto PH = [&](int i) { return phase_clock ? "    PH(" + std::to_string(i) + ");\n" : std::string(); };
+  if (phase_clock && !call_mode)
+    s << "__device__ unsigned long long fs_phase_clk[8];\n"
+         "#define PH(i) { const unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_##i += t_ - ph_last_; ph_last_ = t_; }\n"
+         "#define PH_FLUSH(i) atomicAdd(&fs_phase_clk[i], ph_acc_##i)\n";
   if (call_mode)
     s << "#define NMEM " << N << "\n#define NSEQ_CT " << std::max(1, (int)std::count(m.sequenced.begin(), m.sequenced.end(), 1)) << "\n"
       // (measured, ns per 1 M sites, hoisted / formed again: sum-product form 5 members 125 / 133, trio 70 / 77, quad 96 / 103, ten 252 with
@@ -878,7 +882,7 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
       << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n" + PH(7) + "    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
                     : std::string("    STAGE_OUT(post_g);\n"))
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
-      << PH(5) << (phase_clock ? "  }\n  if ((tid & 63) == 0 && call_g->phase_clk) { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); PH_FLUSH(7); }\n}\n" : "  }\n}\n");
+      << PH(5) << (phase_clock ? std::string("  }\n  if ((tid & 63) == 0") + (call_mode ? " && call_g->phase_clk" : "") + ") { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); PH_FLUSH(7); }\n}\n" : std::string("  }\n}\n"));
   } else {
     // Outputs are staged through the same LDS rows as the input (coalesced 8 B/lane stores).
     // Writing each lane's row straight from registers was measured 20 % slower on MI355X
@@ -933,7 +937,7 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
       << (call_mode ? "    if (call_g->fpp) { STAGE_OUT_CALL(call_g->fpp); }\n" + PH(7) + "    if (call_g->fgt) { STAGE_FGT(call_g->fgt); }\n"
                     : std::string("    STAGE_OUT(post_g);\n"))
       << "    if (status_g && tid < ns) status_g[site0 + tid] = single_fail ? 1 : (!full ? 0x80 : (bn_fail ? 2 : 0));\n"
-      << PH(5) << (phase_clock ? "  }\n  if ((tid & 63) == 0 && call_g->phase_clk) { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); PH_FLUSH(7); }\n}\n" : "  }\n}\n");
+      << PH(5) << (phase_clock ? std::string("  }\n  if ((tid & 63) == 0") + (call_mode ? " && call_g->phase_clk" : "") + ") { PH_FLUSH(0); PH_FLUSH(1); PH_FLUSH(2); PH_FLUSH(3); PH_FLUSH(4); PH_FLUSH(5); PH_FLUSH(6); PH_FLUSH(7); }\n}\n" : std::string("  }\n}\n"));
   }
   return s.str();
 }

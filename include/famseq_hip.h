@@ -159,6 +159,8 @@ const char *famseq_last_error(famseq_ctx *ctx);
  *                   members' genotypes; the group sums through LDS); -1 (default) = chosen per call from
  *                   the batch size.  At most the number of looped members of the pedigree's enumeration
  *                   (famseq_plan_json "enum_group_digits_max"; 0 for pedigrees of up to 6 members)
+ *   "phase_clock_report"  measuring aid: with FAMSEQ_PHASE_CLOCK=1 in the environment the generated kernels carry cycle marks between
+ *                   their phases; this prints the plain kernels' shares (wave cycles per phase) on stderr and clears them
  *   "call_kernels"  1 = build the generated kernels' fused call-path forms now (famseq_bn_call_batch would on
  *                   its first call)
  *   "engine"        FAMSEQ_ENGINE_ENUM (default) or FAMSEQ_ENGINE_ELIM; selecting ELIM generates the
