@@ -1,5 +1,6 @@
-# tools/call_group_ab.sh — call-path kernels: logarithms per basic block (FAMSEQ_CALL_PHRED_GROUP) x constant-width stage-out
-# (FAMSEQ_CALL_CT_OUT), enumeration and sum-product forms, small pedigrees (GPU box)
+# tools/call_group_ab.sh — round 3 experiment (profiles/r03c/exp_call_phred_group_x_ct_out.txt): call-path kernels by logarithms per basic
+# block (FAMSEQ_CALL_PHRED_GROUP) x constant-width stage-out (then an environment switch, FAMSEQ_CALL_CT_OUT; since folded into the
+# kernels' variant contest: kElimCallVariants) x lane kernels' waves per SIMD, small pedigrees (GPU box)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for cfg in "2 1 0" "1 1 0" "2 0 0" "1 0 0" "2 1 2" "1 1 2"; do
