@@ -108,17 +108,20 @@ def make_line(rng, k, pos):
 
 
 def underflowing(a, b):
-    """Both Phred values beyond 3000, i.e. probabilities below 1e-300: at and below the smallest normal double (1e-308 = Phred 3076)
-    a product keeps fewer and fewer bits, and which of them depends on the order of the factors (seed 341: 3130.96 against the
-    reference's 3130.23 for a posterior of 1e-313).  There the two need only agree to 1 %, and an exact zero (99999) on one side may
-    be anything below 1e-250 on the other."""
+    """Both Phred values far out, i.e. probabilities that only exist as products near the smallest normal double (1e-308 = Phred
+    3076): there a product keeps fewer and fewer bits, and which of them depends on the order of the factors (seed 341: 3130.96
+    against the reference's 3130.23 for a posterior of 1e-313).  There the two need only agree to 1 %, and an exact zero (99999) on
+    one side may be anything below 1e-250 on the other."""
     try:
         x, y = float(a), float(b)
     except ValueError:
         return False
     if max(x, y) == 99999:  # a zero on one side: an intermediate product underflowed there (the reference's peeling multiplies messages
         return min(x, y) > 2500  # of 1e-100 and less before it normalises: seed 395, 2804.01 here against its 99999)
-    return min(x, y) > 3000 and abs(x - y) <= 0.01 * max(x, y)
+    # ... and a posterior below 1e-150 is a sum of configuration weights that are themselves products of likelihoods like 1e-162
+    # (PL 1623) and less: the products pass 1e-308 in one order of the factors and not in another (seed 956, -method 1: 2321.49
+    # against 2321.71, the normaliser being 1e-76)
+    return min(x, y) > 1500 and abs(x - y) <= 0.01 * max(x, y)
 
 
 def same_output(got_path, ref_path):
