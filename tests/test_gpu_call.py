@@ -143,3 +143,30 @@ def test_caller_names_other_columns_than_the_sequenced_set(label, opt, cols):
             rec = text[i, j]
             want = "%g,%g,%g:%g,%g,%g:%s\t" % (tuple(gpp[i, j]) + tuple(fpp[i, j]) + ({0: "0/0", 1: "0/1"}.get(int(fgt[i, j]), "1/1"),))
             assert bytes(rec[:rec[-1]]) == want.encode(), (i, j)
+
+
+@pytest.mark.parametrize("label,opt", CALL_ENGINES, ids=[e[0] for e in CALL_ENGINES])
+def test_any_output_may_be_null(label, opt):
+    """famseq_bn_call_batch with some of gpp / fpp / fgt / status NULL (straight through ctypes): what is asked for is what the
+    full call returns."""
+    import ctypes as C
+
+    ped = fs.synthetic_pedigree("ped10")
+    s = 3000 if opt.get("enum_impl") != 0 else 300
+    mo, fa = ped.relations()
+    pl, known, _ = fs.synth.gen_sites(mo, fa, s, seed=fs.synth.SEED_BASE + 9)
+    pl16, flags = np.ascontiguousarray(pl.astype(np.uint16)), known.astype(np.uint8)
+    seq = np.arange(ped.n, dtype=np.int32)
+    ctx = fs.Context(fs.make_model(ped), **opt)
+    full = ctx.bn_call_batch(seq, pl16=pl16, flags=flags)
+    L, p = fs.lib(), lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    for want in ((0, 0, 1, 0), (1, 0, 0, 1), (0, 1, 0, 0), (0, 1, 1, 1)):
+        gpp, fpp = np.full((s, ped.n, 3), -7.0), np.full((s, ped.n, 3), -7.0)
+        fgt, st = np.full((s, ped.n), 9, np.int8), np.full(s, 77, np.uint8)
+        rc = L.famseq_bn_call_batch(ctx._h, s, None, p(pl16, C.c_uint16), p(flags, C.c_uint8), p(seq, C.c_int32), ped.n,
+                                    p(gpp, C.c_double) if want[0] else None, p(fpp, C.c_double) if want[1] else None,
+                                    p(fgt, C.c_int8) if want[2] else None, p(st, C.c_uint8) if want[3] else None)
+        assert rc == 0
+        for got, ref, asked, untouched in ((gpp, full[0], want[0], -7.0), (fpp, full[1], want[1], -7.0), (fgt, full[2], want[2], 9), (st, full[3], want[3], 77)):
+            assert np.array_equal(got, ref) if asked else np.all(got == untouched), (label, want)
+    ctx.close()
