@@ -207,8 +207,9 @@ def side_config(fs, torch, dev, stream, workload, steps, warmup, sites=0):
     plan = ctx.plan()
     probe = stream_probe_GBps(fs, torch, ctx, lk, post, single, stream)
     ctx.close()
-    return {"workload": "BASELINE.json %s: %s, %d seeded synthetic sites, %d-member pedigree (3^%d = %d configs/site)"
-                        % (CONFIG_OF[workload], workload, S, n, n, 3 ** n),
+    return {"workload": "%s: %s, %d seeded synthetic sites, %d-member pedigree (3^%d = %d configs/site)"
+                        % ("not a BASELINE configuration" if CONFIG_OF[workload].startswith("(none") else "BASELINE.json " + CONFIG_OF[workload],
+                           workload, S, n, n, 3 ** n),
             "value": S * steps / elapsed, "unit": "sites/s", "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "outputs_valid": ok,
             "roofline": {"bound": "hbm", "achieved": S * bps / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -671,6 +672,10 @@ def main():
             out["configs_4_ped15"] = side_config(fs, torch, dev, stream, "ped15", 2, 1)
             # beyond the enumeration: the 32-member pedigree through the sum-product engine (4.6 GB of traffic per step)
             out["elim_N32"] = side_wide(fs, torch, dev, stream, 32, max(a.steps, 10), max(a.warmup, 3), 2_000_000)
+            # the shapes most real callers have (not BASELINE configurations): trios and quads, 8 M sites each (streaming from HBM)
+            out["common_pedigrees"] = {w: {k: v for k, v in side_config(fs, torch, dev, stream, w, max(a.steps, 10), max(a.warmup, 3)).items()
+                                           if k in ("workload", "value", "unit", "ms_per_step", "outputs_valid", "roofline")}
+                                       for w in ("trio", "quad")}
             # what the command line launches: the fused call path on packed PLs, and the text records behind it
             out["call_path"] = side_call_path(fs, torch, dev, stream, "ped10", max(a.steps, 20), max(a.warmup, 5), 1_000_000)
         if not a.no_cpu_baseline and world == 1:
