@@ -611,22 +611,65 @@ const char kCallArgs[] = ", const struct fs_call_args *__restrict__ call_g";
 // Statements of the single posterior (family.cpp:1426-1445) and of the shortcut vote (:767-789), the
 // same as in bn_kernel.hip; they read l<p>_<g> and tcf[], set single_fail / full, and (store) write
 // the normalised rows to row[].  Shared by every generated shell.
+// The single posterior's three quotients p0 / s, p1 / s, p2 / s (family.cpp:1437-1441) — bit for bit what `/` gives, at half its cost.
+// hipcc's fp64 division is v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (four FMAs), q = n r, e = fma(-d, q, n),
+// v_div_fmas (an FMA: fma(e, r, q)) and v_div_fixup: eleven instructions, of which v_div_scale (moving extreme operands into range)
+// is the identity and v_div_fixup (zeros, infinities, denormal results) a copy whenever every operand and intermediate is a normal
+// number anyway.  FS_DIV_OK says when that is certain — every numerator >= 2^-300, the common denominator <= 2^300 (it is >= a
+// numerator) — and FS_DIV3_FAST then runs the SAME sequence with the reciprocal's five instructions done once for the three
+// quotients: 14 + 5 for the test instead of 33 (and one quarter-rate v_rcp_f64 instead of three).  Anything else — a likelihood of
+// exactly 0, a huge LK-file scale — takes the plain divisions.  Divisions were a quarter of a small pedigree's instructions:
+// quad 0.556 -> 0.526, five members 0.714 -> 0.679 ms per 8 M sites before the test was added.  (A host build of this text
+// defines both macros itself: FS_DIV_OK 0.)
+const char kDiv3Text[] = R"(
+#ifndef FS_DIV_OK
+#define FS_DIV_OK(p0, p1, p2, s) ((__builtin_fmin(__builtin_fmin((p0), (p1)), (p2)) >= 0x1p-300) & ((s) <= 0x1p300))
+#define FS_DIV3_FAST(p0, p1, p2, s, o0, o1, o2) { double r_ = __builtin_amdgcn_rcp(s), e_ = __builtin_fma(-(s), r_, 1.0); \
+    r_ = __builtin_fma(r_, e_, r_); e_ = __builtin_fma(-(s), r_, 1.0); r_ = __builtin_fma(r_, e_, r_); \
+    const double t0_ = (p0) * r_, t1_ = (p1) * r_, t2_ = (p2) * r_; \
+    o0 = __builtin_fma(__builtin_fma(-(s), t0_, (p0)), r_, t0_); o1 = __builtin_fma(__builtin_fma(-(s), t1_, (p1)), r_, t1_); \
+    o2 = __builtin_fma(__builtin_fma(-(s), t2_, (p2)), r_, t2_); }
+#endif
+)";
+
 std::string single_posterior_statements(const Model &m, bool flags_pass, bool store, bool fence_single, const char *dst) {
   std::ostringstream s;
   const int N = m.n_members;
-  for (int p = 0; p < N; ++p) {
-    const int fk = m.gender[p] == 1 ? 0 : 1;
-    s << "    { const double a0 = l" << p << "_0, a1 = l" << p << "_1, a2 = l" << p << "_2;\n"
-      << "      const double p0 = a0 * tcf[" << fk * 27 << "], p1 = a1 * tcf[" << fk * 27 + 9 << "], p2 = a2 * tcf["
-      << fk * 27 + 18 << "];\n      const double s = (p0 + p1) + p2;";
-    if (flags_pass) s << " if (s <= 0) single_fail = true;";
-    s << "\n";
-    if (store)
-      s << "      " << dst << "[" << 3 * p << "] = p0 / s; " << dst << "[" << 3 * p + 1 << "] = p1 / s; " << dst << "[" << 3 * p + 2 << "] = p2 / s;\n";
-    if (flags_pass && m.sequenced[p])
-      s << "      double big = 0; if (big < a0) big = a0; if (big < a1) big = a1; if (big < a2) big = a2;\n"
-        << "      const double sum = (a0 + a1) + a2; big = big / sum; if (big < lc) full = true;\n";
-    // fence: one member at a time (interleaved division sequences would spill)
+  // members in groups of four (one at a time in the fenced variants: interleaved division sequences would spill): the products
+  // and sums of the group, ONE test and branch for its quotients, then the shortcut vote's part
+  const int G = fence_single ? 1 : 4;
+  for (int lo = 0; lo < N; lo += G) {
+    const int hi = std::min(N, lo + G);
+    s << "    {\n";
+    for (int p = lo; p < hi; ++p) {
+      const int fk = m.gender[p] == 1 ? 0 : 1;
+      const std::string k = std::to_string(p);
+      s << "      const double a" << k << "_0 = l" << p << "_0, a" << k << "_1 = l" << p << "_1, a" << k << "_2 = l" << p << "_2;\n"
+        << "      const double p" << k << "_0 = a" << k << "_0 * tcf[" << fk * 27 << "], p" << k << "_1 = a" << k << "_1 * tcf[" << fk * 27 + 9
+        << "], p" << k << "_2 = a" << k << "_2 * tcf[" << fk * 27 + 18 << "];\n      const double s" << k << " = (p" << k << "_0 + p" << k
+        << "_1) + p" << k << "_2;";
+      if (flags_pass) s << " if (s" << k << " <= 0) single_fail = true;";
+      s << "\n";
+    }
+    if (store) {
+      s << "      if (";
+      for (int p = lo; p < hi; ++p)
+        s << (p > lo ? " & " : "") << "FS_DIV_OK(p" << p << "_0, p" << p << "_1, p" << p << "_2, s" << p << ")";
+      s << ") {\n";
+      for (int p = lo; p < hi; ++p)
+        s << "        FS_DIV3_FAST(p" << p << "_0, p" << p << "_1, p" << p << "_2, s" << p << ", " << dst << "[" << 3 * p << "], " << dst << "["
+          << 3 * p + 1 << "], " << dst << "[" << 3 * p + 2 << "]);\n";
+      s << "      } else {\n";
+      for (int p = lo; p < hi; ++p)
+        s << "        " << dst << "[" << 3 * p << "] = p" << p << "_0 / s" << p << "; " << dst << "[" << 3 * p + 1 << "] = p" << p << "_1 / s" << p
+          << "; " << dst << "[" << 3 * p + 2 << "] = p" << p << "_2 / s" << p << ";\n";
+      s << "      }\n";
+    }
+    for (int p = lo; p < hi; ++p)
+      if (flags_pass && m.sequenced[p])
+        s << "      { double big = 0; if (big < a" << p << "_0) big = a" << p << "_0; if (big < a" << p << "_1) big = a" << p << "_1; if (big < a"
+          << p << "_2) big = a" << p << "_2;\n"
+          << "        const double sum = (a" << p << "_0 + a" << p << "_1) + a" << p << "_2; big = big / sum; if (big < lc) full = true; }\n";
     s << "    }\n";
     if (fence_single) s << "    asm volatile(\"\" ::: \"memory\");\n";
   }
@@ -679,6 +722,7 @@ std::string kernel_shell(const Model &m, const std::string &entry, const std::st
     // every barrier would wait for this wave's global stores to reach memory; nothing here hands
     // global data between lanes, so only the LDS counter has to be zero.
     << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
+    << kDiv3Text
     // Staging between global memory and the padded LDS rows.  Element e of the chunk (e = site-in-
     // chunk * W3 + column) lives at LDS index a = (e / W3) * ROW + e % W3.
     // Whole chunks (all but the last of a launch) take a branch-free, fully unrolled walk: quotient
@@ -959,7 +1003,8 @@ std::string direct_shell(const Model &m, const std::string &comment, const std::
   s << "// generated by famseq_amd/csrc for a " << N << "-member pedigree: " << comment << "\n"
     << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n#pragma clang fp contract(off)\n"
     << "#define W3 " << W3 << "\n#define BT " << bt << "\n"
-    << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n";
+    << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
+    << kDiv3Text;
   if (lean)  // a likelihood is read from the lane's row in global memory at each use (volatile: never kept in a register)
     for (int p = 0; p < N; ++p)
       for (int gt = 0; gt < 3; ++gt) s << "#define l" << p << "_" << gt << " lgv[" << 3 * p + gt << "]\n";

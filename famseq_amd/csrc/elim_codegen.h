@@ -35,6 +35,7 @@ int elim_first_variant(const Model &m, bool call_mode = false);  // where jit_pi
 // Shared shell of the generated kernels (see elim_codegen.cpp).
 extern const std::string kCallHelpers;  // fused call path: fs_phred, STAGE_IN_PL, STAGE_OUT_CALL, STAGE_FGT
 extern const char kCallArgs[];     // ... and the kernel arguments that go with them
+extern const char kDiv3Text[];     // FS_DIV_OK / FS_DIV3_FAST: what single_posterior_statements' text needs defined
 std::string single_posterior_statements(const Model &m, bool flags_pass, bool store, bool fence_single, const char *dst = "row");
 std::string kernel_shell(const Model &m, const std::string &entry, const std::string &comment,
                          const std::string &body, int bt, int min_waves, bool regs_l, bool fence_single,

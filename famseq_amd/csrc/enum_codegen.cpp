@@ -824,6 +824,7 @@ std::string grouped_shell(const Model &m, const std::string &comment, const std:
     << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n#pragma clang fp contract(off)\n"
     << "#define W3 " << W3 << "\n#define ROW " << ROW << "\n#define BT " << bt << "\n#define G " << group << "\n#define SPC (BT / G)\n"
     << "#define LDS_BARRIER() asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\")\n"
+    << kDiv3Text
     // rows of the groups' first lanes -> global, coalesced
     << "#define STAGE_OUT(Gp) { double *g_ = (Gp) + site0 * W3; \\\n"
     << "  for (int e = tid; e < ns * W3; e += BT) { const int s_ = e / W3; g_[e] = s_io[s_ * G * ROW + (e - s_ * W3)]; } }\n"

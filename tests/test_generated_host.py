@@ -83,8 +83,14 @@ extern "C" void famseq_enum_lane(const double *lk, const unsigned char *fl, doub
 """
 
 
+# The single posterior's quotients: on the device three divisions share one refined reciprocal where every intermediate is a normal
+# number (csrc/elim_codegen.cpp kDiv3Text: the compiler's own division sequence, bit for bit); a host build takes the plain divisions.
+HOST_DIV = "#define FS_DIV_OK(p0, p1, p2, s) 0\n#define FS_DIV3_FAST(p0, p1, p2, s, o0, o1, o2) (void)0\n"
+
+
 def portable(src: str) -> str:
     """Device-only spellings both shims replace: compiler pins (no arithmetic in them) and clang's vector types."""
+    src = src.replace("#pragma clang fp contract(off)", "#pragma clang fp contract(off)\n" + HOST_DIV, 1)
     src = re.sub(r"#define FS_HIDE_LANE\(t_\).*", "#define FS_HIDE_LANE(t_) (void)0", src)
     src = src.replace("typedef unsigned fs_v4u __attribute__((ext_vector_type(4)));", "struct fs_v4u { unsigned x, y, z, w; };")
     return src.replace("__builtin_amdgcn_sched_barrier(0);", "")

@@ -388,3 +388,50 @@ def test_sharded_entry_point_over_two_contexts():
         x.close()
     with pytest.raises(fs.FamseqError, match="no CPU path"):
         fs.bn_batch_sharded([fs.Context(model, device=-1)], lk[:4], flags[:4])
+
+
+@pytest.mark.parametrize("name,n_sites", [("trio", 600_000), ("quad", 400_000), ("ped5", 300_000), ("ped10", 20_000)])
+def test_single_posterior_quotients_are_the_divisions_bits(name, n_sites):
+    """The generated kernels form the single posterior's three quotients per member with ONE refined reciprocal where every
+    intermediate is a normal number (elim_codegen.cpp kDiv3Text: the compiler's own division sequence with its scaling steps
+    left out where they are the identity) and with plain divisions elsewhere; the compiled-in team kernel divides.  Likelihoods
+    over the whole exponent range — down to the sub-normals, exact zeros, values above 1 (an LK file's scale), a member with all
+    three tiny — every flag combination: the same bits, site for site, from the enumeration and the sum-product kernel."""
+    ped = fs.synthetic_pedigree(name)
+    rng = np.random.RandomState(42)
+    lk = 10.0 ** (-rng.uniform(0, 300, size=(n_sites, ped.n, 3)) * (rng.random_sample((n_sites, ped.n, 1)) < 0.5))
+    lk[rng.random_sample(lk.shape) < 0.01] = 0.0
+    lk[rng.random_sample(lk.shape) < 0.01] *= 1e6
+    tiny = rng.random_sample((n_sites, ped.n)) < 0.01
+    lk[tiny] = lk[tiny] * 1e-305
+    huge = rng.random_sample((n_sites, ped.n)) < 0.002
+    lk[huge] = lk[huge] * 1e302
+    flags = rng.randint(0, 4, n_sites).astype(np.uint8)
+    model = fs.make_model(ped)
+    want = None
+    for label, opt in (("team", dict(enum_impl=0)), ("lane", dict(enum_impl=1)), ("elim", dict(engine=fs.ENGINE_ELIM))):
+        if label == "team" and name == "ped10":
+            continue
+        ctx = fs.Context(model, **opt)
+        _, single, st = ctx.bn_batch(lk[:n_sites if label != "team" else min(n_sites, 100_000)], flags[:n_sites if label != "team" else min(n_sites, 100_000)])
+        ctx.close()
+        if want is None:
+            want = (single, st)
+            continue
+        k = min(len(st), len(want[1]))
+        assert np.array_equal(st[:k] & 1, want[1][:k] & 1), label
+        ok = (st[:k] & 3) != 1
+        assert np.array_equal(single[:k][ok].view(np.uint64), want[0][:k][ok].view(np.uint64)), label
+    # and against numpy's IEEE divisions of the same products (family.cpp:1426-1445), on the sites whose single posterior exists
+    single, st = want
+    k = len(st)
+    m = model
+    autos = (flags[:k] & 2) == 0
+    prior = np.where(((flags[:k] & 1) != 0)[:, None], np.array(list(m.genoProbK))[None, :], np.array(list(m.genoProbN))[None, :])
+    p = lk[:k] * prior[:, None, :]
+    s = (p[:, :, 0] + p[:, :, 1]) + p[:, :, 2]
+    with np.errstate(all="ignore"):
+        ref = p / s[:, :, None]
+    sel = autos & ((st & 3) != 1)
+    assert sel.sum() > 1000
+    assert np.array_equal(single[sel].view(np.uint64), ref[sel].view(np.uint64))
