@@ -637,7 +637,14 @@ std::string single_posterior_statements(const Model &m, bool flags_pass, bool st
   const int N = m.n_members;
   // members in groups of four (one at a time in the fenced variants: interleaved division sequences would spill): the products
   // and sums of the group, ONE test and branch for its quotients, then the shortcut vote's part
-  const int G = fence_single ? 1 : 4;
+  // (wide pedigrees, whose registers hold 3 N likelihoods: one at a time as well — four members' products pushed the 32-member
+  // kernel's fence-free variant into scratch and the contest onto the fenced one, 1.06-1.13 -> 1.21 ms per 2 M sites)
+  int G = fence_single || N > 12 ? 1 : 4;
+  if (const char *e = std::getenv("FAMSEQ_DIV_GROUP")) G = std::max(1, std::atoi(e));  // tuning aid
+  // (beyond twelve members — one member at a time, a branch each — it is a wash: fifteen members -2 %, 24: -1 %, 32: +2.5 %, 48: -4 %
+  // per 2 M sites; plain divisions there)
+  bool div_fast = N <= 12;
+  if (const char *e = std::getenv("FAMSEQ_DIV_FAST")) div_fast = std::atoi(e) != 0;  // tuning aid: 0 = plain divisions everywhere
   for (int lo = 0; lo < N; lo += G) {
     const int hi = std::min(N, lo + G);
     s << "    {\n";
@@ -654,7 +661,7 @@ std::string single_posterior_statements(const Model &m, bool flags_pass, bool st
     if (store) {
       s << "      if (";
       for (int p = lo; p < hi; ++p)
-        s << (p > lo ? " & " : "") << "FS_DIV_OK(p" << p << "_0, p" << p << "_1, p" << p << "_2, s" << p << ")";
+        s << (p > lo ? " & " : "") << (div_fast ? "FS_DIV_OK(p" : "0 && FS_DIV_OK(p") << p << "_0, p" << p << "_1, p" << p << "_2, s" << p << ")";
       s << ") {\n";
       for (int p = lo; p < hi; ++p)
         s << "        FS_DIV3_FAST(p" << p << "_0, p" << p << "_1, p" << p << "_2, s" << p << ", " << dst << "[" << 3 * p << "], " << dst << "["
